@@ -1,0 +1,128 @@
+/* mgb_hip.h -- C ABI of libmgb_hip.so, the MI355X-native multigrid-barrier Newton path.
+ *
+ * Drop-in boundary for the distributed path of sloisel/MultiGridBarrierMPI.jl: each entry point
+ * names the reference interface it replaces (file:line relative to the reference repository,
+ * src = src/MultiGridBarrierMPI.jl).  All functions return 0 on success or a negative MGB_E_* code;
+ * mgb_last_error() returns the message of the last failure on the calling thread.  Nothing throws
+ * or aborts across this boundary.  The library owns all device memory behind opaque handles; the
+ * caller owns every host buffer.  One host thread drives one context; calls are not re-entrant
+ * per context (mirrors "all functions are collective", docs/src/guide.md:63-81).
+ *
+ * Matrices cross the boundary as CSR with Int32 indices (0-based) and fp64 values -- the layout of
+ * the local row block of an HPCSparseMatrix (test/test_dump_matrices.jl:62-71; Ti=Int32 src:260).
+ * Dense n x k matrices are row-major unless stated; `z` is the Julia `vec` of the n x S state matrix
+ * (column-major, [u; s]).
+ */
+#ifndef MGB_HIP_H
+#define MGB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGB_OK 0
+#define MGB_E_ARG (-1)      /* bad argument / unknown name / shape mismatch */
+#define MGB_E_HIP (-2)      /* HIP runtime failure, or no GPU visible (there is no CPU fallback) */
+#define MGB_E_NUMERIC (-3)  /* solver breakdown: non-SPD Hessian, infeasible start, kappa collapse */
+#define MGB_E_INTERNAL (-4)
+
+typedef struct mgb_ctx_s* mgb_ctx;   /* device + stream; replaces the HPCBackend instance (src:84-114) */
+typedef struct mgb_geo_s* mgb_geo;   /* native Geometry (host); fields of src:318-330 */
+typedef struct mgb_amg_s* mgb_amg;   /* AMG hierarchy + barrier problem resident in HBM */
+typedef struct mgb_vec_s* mgb_vec;   /* device fp64 vector  == HPCVector.v (src:175) */
+typedef struct mgb_csr_s* mgb_csr;   /* device CSR          == HPCSparseMatrix local block (src:216-221) */
+
+const char* mgb_last_error(void);
+int mgb_version(void);
+/* number of visible HIP devices (0 when there is no GPU); never fails */
+int mgb_device_count(void);
+
+/* ---- context ------------------------------------------------------------------------------- */
+int mgb_ctx_create(int device_id, mgb_ctx* out);
+int mgb_ctx_destroy(mgb_ctx ctx);
+int mgb_ctx_synchronize(mgb_ctx ctx);
+
+/* ---- native geometry (host, setup time) ---------------------------------------------------- *
+ * fem1d / fem2d are MultiGridBarrier's geometry builders, called at src:561 and src:628 before
+ * native_to_mpi.  K: 3m x 2 row-major coarse triangle vertices or NULL for the default square. */
+int mgb_fem1d_native(int L, mgb_geo* out);
+int mgb_fem2d_native(int L, const double* K, int nK_rows, mgb_geo* out);
+/* A Geometry assembled by the caller (native_to_mpi input, src:259-302): create, then add matrices.
+ * names: "op:<key>" (n x n), "sub:<key>:<level>" (n x m_l, level 0 = coarsest),
+ *        "refine:<level>", "coarsen:<level>".  block = rows per element (1 if unknown). */
+int mgb_geo_create(int n, int dim, int L, int block, const double* x, const double* w, mgb_geo* out);
+int mgb_geo_set_matrix(mgb_geo g, const char* name, int rows, int cols, const int32_t* rowptr,
+                       const int32_t* colidx, const double* vals);
+int mgb_geo_destroy(mgb_geo g);
+int mgb_geo_dims(mgb_geo g, int* n, int* dim, int* L, int* block);
+int mgb_geo_get_xw(mgb_geo g, double* x, double* w);          /* mpi_to_native(geometry), src:355-407 */
+int mgb_geo_matrix_info(mgb_geo g, const char* name, int* rows, int* cols, int* nnz);
+int mgb_geo_matrix_get(mgb_geo g, const char* name, int32_t* rowptr, int32_t* colidx, double* vals);
+
+/* ---- device vectors / sparse matrices: the array algebra MultiGridBarrier applies - */
+int mgb_vec_create(mgb_ctx ctx, int n, const double* host_or_null, mgb_vec* out);  /* HPCVector(v, backend) src:268; amgb_zeros src:116 */
+int mgb_vec_free(mgb_vec v);
+int mgb_vec_len(mgb_vec v, int* n);
+int mgb_vec_upload(mgb_vec v, const double* host);
+int mgb_vec_download(mgb_vec v, double* host);                /* Vector(x) gather, src:360; _to_cpu_array src:183-188 */
+int mgb_csr_create(mgb_ctx ctx, int rows, int cols, const int32_t* rowptr, const int32_t* colidx,
+                   const double* vals, mgb_csr* out);         /* HPCSparseMatrix(S, backend) src:271 */
+int mgb_csr_free(mgb_csr A);
+int mgb_diag(mgb_ctx ctx, mgb_vec z, int m, int n, mgb_csr* out);  /* amgb_diag: spdiagm(m,n,0=>z) src:137-147 */
+int mgb_spmv(mgb_csr A, mgb_vec x, mgb_vec y);                /* y = A*x   (HPCSparseMatrix * HPCVector, test_nonsquare.jl:43) */
+int mgb_spmv_add(mgb_csr A, mgb_vec x, mgb_vec y0, mgb_vec y); /* y = y0 + A*x */
+int mgb_dot(mgb_vec x, mgb_vec y, double* out);               /* dot(w,y) tools/profile_scaling.jl:102 */
+int mgb_mul(mgb_vec x, mgb_vec y, mgb_vec out);               /* w .* col, test_column_extract.jl:65 */
+int mgb_axpy(mgb_vec x, double alpha, mgb_vec y, mgb_vec out); /* out = x + alpha*y */
+int mgb_all_isfinite(mgb_vec x, int* out);                    /* amgb_all_isfinite src:121-133 */
+
+/* ---- AMG + barrier problem ------------------------------------------------------------------ *
+ * state_vars: S pairs "name\0subspace\0" flattened as 2*S C strings; D: K pairs (state var, operator)
+ * (amg(geometry; state_variables, D): layout test/test_d0_construction.jl:82-100).
+ * Barrier: power cone {(q,s): s >= |q|^p} on D rows idx_q[0..nq) and idx_s (convex_Euclidian_power).
+ * Uploads the geometry to HBM (the native_to_mpi step, src:259-338) and builds every level. */
+int mgb_amg_create(mgb_ctx ctx, mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D,
+                   int nq, const int* idx_q, int idx_s, double p, mgb_amg* out);
+int mgb_amg_destroy(mgb_amg a);
+int mgb_amg_dims(mgb_amg a, int* n, int* S, int* K, int* L, int* nY);
+int mgb_amg_level_size(mgb_amg a, int level, int* N, int* nnz_lower);
+int mgb_amg_hessian_pattern(mgb_amg a, int level, int32_t* rowptr, int32_t* colidx);  /* lower triangle of R'HR */
+int mgb_amg_set_c(mgb_amg a, const double* c);     /* n x K row-major cost (f_grid) */
+int mgb_amg_set_z(mgb_amg a, const double* z);     /* S*n, [u; s] */
+int mgb_amg_get_z(mgb_amg a, double* z);           /* mpi_to_native(sol).z, src:422-474 */
+/* barrier(F).f0/f1/f2 at level `level`, subspace coordinates s (N_l host values), parameter t:
+ *   f0: test/test_apply_d.jl:44 + tools/profile_barrier.jl:45-59; parts = {sum w F, sum w c.Dz}
+ *   f1: test/test_column_extract.jl:50-80;  f2: test/test_map_rows_compare.jl:102-123,165-170 */
+int mgb_amg_apply_D(mgb_amg a, int level, const double* s, double* Dz /* n x K */);
+int mgb_amg_f0(mgb_amg a, int level, const double* s, double t, double* y, double* parts2);
+int mgb_amg_f1(mgb_amg a, int level, const double* s, double t, double* g);
+int mgb_amg_f2(mgb_amg a, int level, const double* s, double t, double* lower_vals);
+/* MultiGridBarrier.solve(A, b) = A \ b (test/test_instrumented_solve.jl:25-28,99), host direct solve */
+int mgb_amg_solve_linear(mgb_amg a, int level, const double* lower_vals, const double* g, double* x);
+/* amgb main phase: t-continuation x level loop x Newton; z updated in place */
+int mgb_amg_solve(mgb_amg a, double tol, double t0, double kappa, int maxit, int max_newton, int verbose);
+/* SOL_main fields (docs/src/api.md:97-101) of the last mgb_amg_solve */
+int mgb_amg_sol_info(mgb_amg a, int* nt, double* t_elapsed, double* time_factor, long long* counts4);
+int mgb_amg_sol_get(mgb_amg a, long long* its /* L x nt col-major */, double* ts, double* c_dot_Dz);
+/* per-kernel device timings (HIP events on the context stream), ms and algorithmic bytes per launch:
+ * order = apply_D, barrier_f2, hessian_assemble, barrier_f1, restrict, barrier_f0 */
+int mgb_amg_time_kernels(mgb_amg a, int level, int reps, double* ms6, double* bytes6);
+
+/* ---- host-only symbolic helpers (no GPU needed; used by the CPU test-suite) ----------------- */
+typedef struct mgb_plan_s* mgb_plan;  /* symbolic products of one level: R, B=D*R, B', Hessian plan T */
+int mgb_plan_create(mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D, int nq,
+                    const int* idx_q, int idx_s, int level, mgb_plan* out);
+int mgb_plan_destroy(mgb_plan p);
+int mgb_plan_sizes(mgb_plan p, int* N, int* nnz_lower, int* nnz_T, int* nnz_B);
+int mgb_plan_pattern(mgb_plan p, int32_t* rowptr, int32_t* colidx);
+/* lower_vals = T * vec(Y) evaluated on the host: checks the plan against the reference's Hessian
+ * recipe (test/test_matrix_addition.jl:39-95) in the CPU test-suite; not used by the product path */
+int mgb_plan_eval_host(mgb_plan p, const double* Y /* n x nY */, double* lower_vals);
+int mgb_chol_selftest(int nx, int ny, double* max_residual, double* flops, double* seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGB_HIP_H */

@@ -1,0 +1,582 @@
+"""multigridbarriermpi.jl_amd -- MI355X-native multigrid-barrier Newton path.
+
+Host-side mirror (Python, because no Julia toolchain exists in the build image) of the operator
+surface of sloisel/MultiGridBarrierMPI.jl, on top of the C ABI in ``include/mgb_hip.h``
+(``lib/libmgb_hip.so``, hand-written HIP for gfx950).  Names, argument meaning and error behaviour
+follow the reference (src = /root/reference/src/MultiGridBarrierMPI.jl):
+
+  fem1d_mpi / fem2d_mpi                 src:559-565, 626-632
+  fem1d_mpi_solve / fem2d_mpi_solve     src:594-600, 661-667
+  native_to_mpi / mpi_to_native         src:259-338, 355-517
+  amgb (re-export)                      src:748-752
+  hooks amgb_zeros, amgb_all_isfinite, amgb_diag, amgb_blockdiag, map_rows, map_rows_gpu,
+        _raw_array, _to_cpu_array       src:66-192
+
+There is NO CPU fallback: every entry point that computes needs the HIP library and a GPU and
+raises otherwise.  (The importable alias of this package is ``mgb_amd``; the directory name
+contains a dot and cannot be imported directly.)
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from ._lib import MGBError, call, dptr, f64, i32, iptr
+
+import ctypes as C
+
+__all__ = [
+    "fem1d", "fem2d", "fem1d_mpi", "fem2d_mpi", "fem1d_mpi_solve", "fem2d_mpi_solve", "native_to_mpi",
+    "mpi_to_native", "amgb", "Geometry", "AMGBSOL", "HPCVector", "HPCMatrix", "HPCSparseMatrix",
+    "backend_hip", "amgb_zeros", "amgb_all_isfinite", "amgb_diag", "amgb_blockdiag", "map_rows", "map_rows_gpu",
+    "_raw_array", "_to_cpu_array", "MGBError", "device_count", "AMG", "amg",
+]
+
+
+def device_count() -> int:
+    return int(_lib.load().mgb_device_count())
+
+
+# --------------------------------------------------------------------------- backend / context
+
+
+class HPCBackend:
+    """One GPU + one stream (replaces HPCBackend{T,Ti,Device,Comm,Solver}, src:84-114)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        call("mgb_ctx_create", int(device), C.byref(h))
+        self.handle = h
+        self.device = device
+
+    def synchronize(self):
+        call("mgb_ctx_synchronize", self.handle)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().mgb_ctx_destroy(self.handle)
+        except Exception:
+            pass
+
+
+_BACKENDS: Dict[int, HPCBackend] = {}
+
+
+def backend_hip(device: int = 0) -> HPCBackend:
+    """Cached backend instance per device (the reference caches GPU backends the same way, src:84-110)."""
+    if device not in _BACKENDS:
+        _BACKENDS[device] = HPCBackend(device)
+    return _BACKENDS[device]
+
+
+# --------------------------------------------------------------------------- device array types
+
+
+class HPCVector:
+    """Device fp64 vector (reference HPCVector: `.v` local storage, src:175)."""
+
+    def __init__(self, v, backend: Optional[HPCBackend] = None):
+        backend = backend or backend_hip()
+        self.backend = backend
+        h = C.c_void_p()
+        if isinstance(v, (int, np.integer)):
+            self.n = int(v)
+            call("mgb_vec_create", backend.handle, self.n, None, C.byref(h))
+        else:
+            a = f64(np.asarray(v).reshape(-1))
+            self.n = a.size
+            call("mgb_vec_create", backend.handle, self.n, dptr(a), C.byref(h))
+        self.handle = h
+
+    def __len__(self):
+        return self.n
+
+    @property
+    def shape(self):
+        return (self.n,)
+
+    def to_numpy(self) -> np.ndarray:
+        out = np.empty(self.n)
+        call("mgb_vec_download", self.handle, dptr(out))
+        return out
+
+    def __array__(self, dtype=None):
+        a = self.to_numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def dot(self, other: "HPCVector") -> float:
+        out = C.c_double()
+        call("mgb_dot", self.handle, other.handle, C.byref(out))
+        return out.value
+
+    def __mul__(self, other):          # w .* y  (test/test_column_extract.jl:65)
+        if isinstance(other, HPCVector):
+            out = HPCVector(self.n, self.backend)
+            call("mgb_mul", self.handle, other.handle, out.handle)
+            return out
+        return NotImplemented
+
+    def __add__(self, other):
+        out = HPCVector(self.n, self.backend)
+        call("mgb_axpy", self.handle, 1.0, other.handle, out.handle)
+        return out
+
+    def __sub__(self, other):
+        out = HPCVector(self.n, self.backend)
+        call("mgb_axpy", self.handle, -1.0, other.handle, out.handle)
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().mgb_vec_free(self.handle)
+        except Exception:
+            pass
+
+
+class HPCMatrix:
+    """Device dense n x k matrix, row-major (reference HPCMatrix: `.A`, src:176)."""
+
+    def __init__(self, A, backend: Optional[HPCBackend] = None):
+        A = f64(np.atleast_2d(np.asarray(A)))
+        self.shape = A.shape
+        self.backend = backend or backend_hip()
+        self._v = HPCVector(A.reshape(-1), self.backend)
+
+    def to_numpy(self) -> np.ndarray:
+        return self._v.to_numpy().reshape(self.shape)
+
+    def __array__(self, dtype=None):
+        a = self.to_numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def column(self, j: int) -> HPCVector:   # y[:, j] -> HPCVector (test/test_column_extract.jl:50)
+        return HPCVector(self.to_numpy()[:, j], self.backend)
+
+
+class HPCSparseMatrix:
+    """Device CSR matrix (reference HPCSparseMatrix local block, src:216-221).  A host copy of the
+    structure is kept for `mpi_to_native` (the reference gathers with SparseMatrixCSC(x), src:371)."""
+
+    def __init__(self, S, backend: Optional[HPCBackend] = None):
+        S = sp.csr_matrix(S, dtype=np.float64)
+        S.sort_indices()
+        S.sum_duplicates()
+        self.host = S
+        self.shape = S.shape
+        self.backend = backend or backend_hip()
+        h = C.c_void_p()
+        rp, ci, va = i32(S.indptr), i32(S.indices), f64(S.data)
+        call("mgb_csr_create", self.backend.handle, S.shape[0], S.shape[1], iptr(rp), iptr(ci), dptr(va), C.byref(h))
+        self.handle = h
+
+    def __matmul__(self, x):
+        if isinstance(x, HPCVector):                      # A * x  (test/test_nonsquare.jl:43)
+            y = HPCVector(self.shape[0], self.backend)
+            call("mgb_spmv", self.handle, x.handle, y.handle)
+            return y
+        return NotImplemented
+
+    @property
+    def T(self):                                            # lazy Adjoint in the reference; materialised here
+        return HPCSparseMatrix(self.host.T.tocsr(), self.backend)
+
+    def to_scipy(self):
+        return self.host.copy()
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().mgb_csr_free(self.handle)
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------- hooks (src:62-192)
+
+
+def amgb_zeros(like, m, n=None):
+    """src:66-75,116: zeros with the storage kind of `like`."""
+    if n is None:
+        return HPCVector(int(m), getattr(like, "backend", None))
+    if isinstance(like, HPCSparseMatrix):
+        return HPCSparseMatrix(sp.csr_matrix((m, n)), like.backend)
+    return HPCMatrix(np.zeros((m, n)), getattr(like, "backend", None))
+
+
+def amgb_all_isfinite(z) -> bool:
+    """src:121-133: all(isfinite) on the device, one flag back."""
+    v = z._v if isinstance(z, HPCMatrix) else z
+    out = C.c_int()
+    call("mgb_all_isfinite", v.handle, C.byref(out))
+    return bool(out.value)
+
+
+def amgb_diag(like, z, m=None, n=None) -> HPCSparseMatrix:
+    """src:137-147: spdiagm(m, n, 0 => z) as a device CSR."""
+    backend = getattr(like, "backend", None) or backend_hip()
+    if not isinstance(z, HPCVector):
+        z = HPCVector(z, backend)
+    m = len(z) if m is None else m
+    n = len(z) if n is None else n
+    h = C.c_void_p()
+    call("mgb_diag", backend.handle, z.handle, int(m), int(n), C.byref(h))
+    out = HPCSparseMatrix.__new__(HPCSparseMatrix)
+    zz = z.to_numpy()
+    d = min(m, n, len(zz))
+    out.host = sp.csr_matrix((zz[:d], (np.arange(d), np.arange(d))), shape=(m, n))
+    out.shape = (m, n)
+    out.backend = backend
+    out.handle = h
+    return out
+
+
+def amgb_blockdiag(*mats: HPCSparseMatrix) -> HPCSparseMatrix:
+    """src:150."""
+    return HPCSparseMatrix(sp.block_diag([m.host for m in mats], format="csr"), mats[0].backend)
+
+
+def _raw_array(x):
+    """src:175-176."""
+    return x._v if isinstance(x, HPCMatrix) else x
+
+
+def _to_cpu_array(x):
+    """src:183-188: device -> host copy for scalar indexing."""
+    return x if isinstance(x, np.ndarray) else x.to_numpy()
+
+
+def map_rows(f: Callable, A, *args):
+    """src:161-163.  Row-wise map over co-partitioned arrays; scalar results -> HPCVector, row results
+    -> HPCMatrix.  Arbitrary host closures cannot cross the C ABI: they are evaluated
+    on the host on a device->host copy (the same trade as the reference's `_to_cpu_array`, src:183-188)
+    and the result is uploaded.  The barrier family used on the Newton hot path never goes through
+    here: its F/F1/F2 are the fused HIP kernels behind `AMG.f0/f1/f2`."""
+    arrays = [A, *args]
+    backend = next((a.backend for a in arrays if hasattr(a, "backend")), None)
+    host = [np.asarray(_to_cpu_array(a), dtype=np.float64) for a in arrays]
+    n = host[0].shape[0]
+    rows = []
+    for i in range(n):
+        rows.append(np.asarray(f(*[h[i:i + 1] if h.ndim == 1 else h[i, :] for h in host]), dtype=np.float64))
+    if rows and rows[0].ndim == 0:
+        return HPCVector(np.array([float(r) for r in rows]), backend)
+    return HPCMatrix(np.vstack([r.reshape(1, -1) for r in rows]), backend)
+
+
+def map_rows_gpu(f: Callable, A, *args):
+    """src:168-170."""
+    return map_rows(f, A, *args)
+
+
+# --------------------------------------------------------------------------- Geometry
+
+
+@dataclass
+class Geometry:
+    """MultiGridBarrier `Geometry` fields in the reference's order (src:318-330)."""
+    discretization: dict
+    x: object
+    w: object
+    subspaces: Dict[str, list]
+    operators: Dict[str, object]
+    refine: list
+    coarsen: list
+    _geo: object = field(default=None, repr=False)     # mgb_geo handle (MPI geometries only)
+
+    def __del__(self):
+        try:
+            if self._geo is not None:
+                _lib.load().mgb_geo_destroy(self._geo)
+        except Exception:
+            pass
+
+
+def _geo_matrix(h, name) -> sp.csr_matrix:
+    r, c, nz = C.c_int(), C.c_int(), C.c_int()
+    call("mgb_geo_matrix_info", h, name.encode(), C.byref(r), C.byref(c), C.byref(nz))
+    rp = np.empty(r.value + 1, dtype=np.int32)
+    ci = np.empty(nz.value, dtype=np.int32)
+    va = np.empty(nz.value)
+    call("mgb_geo_matrix_get", h, name.encode(), iptr(rp), iptr(ci), dptr(va))
+    return sp.csr_matrix((va, ci, rp), shape=(r.value, c.value))
+
+
+def _native_from_handle(h, kind, ops) -> Geometry:
+    n, dim, L, block = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    call("mgb_geo_dims", h, C.byref(n), C.byref(dim), C.byref(L), C.byref(block))
+    x = np.empty((n.value, dim.value))
+    w = np.empty(n.value)
+    call("mgb_geo_get_xw", h, dptr(x), dptr(w))
+    operators = {k: _geo_matrix(h, "op:" + k) for k in ops}
+    subspaces = {k: [_geo_matrix(h, "sub:%s:%d" % (k, l)) for l in range(L.value)] for k in ("dirichlet", "full")}
+    refine = [_geo_matrix(h, "refine:%d" % l) for l in range(L.value)]
+    coarsen = [_geo_matrix(h, "coarsen:%d" % l) for l in range(L.value)]
+    disc = dict(kind=kind, L=L.value, dim=dim.value, block=block.value)
+    return Geometry(disc, x, w, subspaces, operators, refine, coarsen)
+
+
+def fem1d(L: int = 4) -> Geometry:
+    """Native 1-D geometry (MultiGridBarrier.fem1d, called at src:561)."""
+    h = C.c_void_p()
+    call("mgb_fem1d_native", int(L), C.byref(h))
+    try:
+        return _native_from_handle(h, "fem1d", ("id", "dx"))
+    finally:
+        call("mgb_geo_destroy", h)
+
+
+def fem2d(L: int = 2, K=None) -> Geometry:
+    """Native 2-D geometry (MultiGridBarrier.fem2d, called at src:628)."""
+    h = C.c_void_p()
+    if K is None:
+        call("mgb_fem2d_native", int(L), None, 0, C.byref(h))
+    else:
+        Kc = f64(K)
+        call("mgb_fem2d_native", int(L), dptr(Kc), int(Kc.shape[0]), C.byref(h))
+    try:
+        return _native_from_handle(h, "fem2d", ("id", "dx", "dy"))
+    finally:
+        call("mgb_geo_destroy", h)
+
+
+def native_to_mpi(g_native: Geometry, Ti=np.int32, backend: Optional[HPCBackend] = None) -> Geometry:
+    """src:259-338: convert a native Geometry to device types.  Keys are visited in sorted order as in
+    the reference (src:276,286).  Index type is Int32 (src:260); other Ti are rejected."""
+    if np.dtype(Ti) != np.dtype(np.int32):
+        raise ValueError("native_to_mpi: only Ti=Int32 is supported by the HIP path")
+    backend = backend or backend_hip()
+    x = f64(np.asarray(g_native.x))
+    if x.ndim == 1:
+        x = x.reshape(-1, 1)
+    w = f64(g_native.w)
+    n, dim = x.shape
+    L = len(g_native.refine)
+    h = C.c_void_p()
+    call("mgb_geo_create", n, dim, L, int(g_native.discretization.get("block", 1)), dptr(x), dptr(w), C.byref(h))
+
+    def put(name, S):
+        S = sp.csr_matrix(S, dtype=np.float64)
+        S.sort_indices()
+        S.sum_duplicates()
+        rp, ci, va = i32(S.indptr), i32(S.indices), f64(S.data)
+        call("mgb_geo_set_matrix", h, name.encode(), S.shape[0], S.shape[1], iptr(rp), iptr(ci), dptr(va))
+        return HPCSparseMatrix(S, backend)
+
+    try:
+        operators = {k: put("op:" + k, g_native.operators[k]) for k in sorted(g_native.operators)}
+        subspaces = {k: [put("sub:%s:%d" % (k, l), S) for l, S in enumerate(g_native.subspaces[k])]
+                     for k in sorted(g_native.subspaces)}
+        refine = [put("refine:%d" % l, S) for l, S in enumerate(g_native.refine)]
+        coarsen = [put("coarsen:%d" % l, S) for l, S in enumerate(g_native.coarsen)]
+    except Exception:
+        call("mgb_geo_destroy", h)
+        raise
+    return Geometry(dict(g_native.discretization), HPCMatrix(x, backend), HPCVector(w, backend), subspaces,
+                    operators, refine, coarsen, _geo=h)
+
+
+def fem1d_mpi(L: int = 4, Ti=np.int32, backend=None) -> Geometry:
+    """src:559-565."""
+    return native_to_mpi(fem1d(L), Ti=Ti, backend=backend)
+
+
+def fem2d_mpi(L: int = 2, K=None, Ti=np.int32, backend=None) -> Geometry:
+    """src:626-632."""
+    return native_to_mpi(fem2d(L, K), Ti=Ti, backend=backend)
+
+
+# --------------------------------------------------------------------------- AMG + amgb
+
+DEFAULT_STATE = (("u", "dirichlet"), ("s", "full"))
+DEFAULT_D = {1: (("u", "id"), ("u", "dx"), ("s", "id")),
+             2: (("u", "id"), ("u", "dx"), ("u", "dy"), ("s", "id"))}
+DEFAULT_F = {1: lambda x: np.array([0.5, 0.0, 1.0]), 2: lambda x: np.array([0.5, 0.0, 0.0, 1.0])}
+DEFAULT_G = {1: lambda x: np.array([x[0], 2.0]), 2: lambda x: np.array([x[0] ** 2 + x[1] ** 2, 100.0])}
+
+
+class AMG:
+    """AMG hierarchy + barrier problem resident in HBM (upstream `amg` + `barrier`)."""
+
+    def __init__(self, geometry: Geometry, state_variables=DEFAULT_STATE, D=None, p: float = 1.0, idx=None):
+        if geometry._geo is None:
+            raise TypeError("AMG needs an MPI geometry (use native_to_mpi / fem*d_mpi)")
+        dim = geometry.discretization["dim"]
+        D = DEFAULT_D[dim] if D is None else D
+        K = len(D)
+        if idx is None:
+            idx = list(range(K - dim - 1, K))       # convex_Euclidian_power(idx=2:dim+2)
+        self.geometry = geometry
+        self.state_variables, self.D, self.p, self.idx = tuple(state_variables), tuple(D), float(p), list(idx)
+        backend = geometry.x.backend
+        iq = (C.c_int * (len(idx) - 1))(*idx[:-1])
+        h = C.c_void_p()
+        call("mgb_amg_create", backend.handle, geometry._geo, len(state_variables), _lib.str_array(state_variables),
+             K, _lib.str_array(D), len(idx) - 1, iq, int(idx[-1]), float(p), C.byref(h))
+        self.handle = h
+        n, S, K_, L, nY = (C.c_int() for _ in range(5))
+        call("mgb_amg_dims", h, C.byref(n), C.byref(S), C.byref(K_), C.byref(L), C.byref(nY))
+        self.n, self.S, self.K, self.L, self.nY = n.value, S.value, K_.value, L.value, nY.value
+
+    def level_size(self, l):
+        N, nz = C.c_int(), C.c_int()
+        call("mgb_amg_level_size", self.handle, l, C.byref(N), C.byref(nz))
+        return N.value, nz.value
+
+    def hessian_pattern(self, l):
+        N, nz = self.level_size(l)
+        rp = np.empty(N + 1, dtype=np.int32)
+        ci = np.empty(nz, dtype=np.int32)
+        call("mgb_amg_hessian_pattern", self.handle, l, iptr(rp), iptr(ci))
+        return rp, ci
+
+    def set_c(self, c):
+        c = f64(c)
+        assert c.shape == (self.n, self.K)
+        call("mgb_amg_set_c", self.handle, dptr(c))
+
+    def set_z(self, z):
+        z = f64(np.asarray(z).reshape(-1))
+        assert z.size == self.n * self.S
+        call("mgb_amg_set_z", self.handle, dptr(z))
+
+    def get_z(self):
+        z = np.empty(self.n * self.S)
+        call("mgb_amg_get_z", self.handle, dptr(z))
+        return z
+
+    def apply_D(self, l, s):
+        s = f64(s)
+        out = np.empty((self.n, self.K))
+        call("mgb_amg_apply_D", self.handle, l, dptr(s), dptr(out))
+        return out
+
+    def f0(self, l, s, t, parts=False):
+        s = f64(s)
+        y = C.c_double()
+        pr = np.empty(2)
+        call("mgb_amg_f0", self.handle, l, dptr(s), float(t), C.byref(y), dptr(pr))
+        return (y.value, pr) if parts else y.value
+
+    def f1(self, l, s, t):
+        s = f64(s)
+        g = np.empty(self.level_size(l)[0])
+        call("mgb_amg_f1", self.handle, l, dptr(s), float(t), dptr(g))
+        return g
+
+    def f2(self, l, s, t):
+        """R'HR as a scipy CSR (full symmetric), assembled on the GPU."""
+        s = f64(s)
+        N, nz = self.level_size(l)
+        vals = np.empty(nz)
+        call("mgb_amg_f2", self.handle, l, dptr(s), float(t), dptr(vals))
+        rp, ci = self.hessian_pattern(l)
+        Lo = sp.csr_matrix((vals, ci, rp), shape=(N, N))
+        return Lo + sp.tril(Lo, -1).T, vals
+
+    def solve_linear(self, l, lower_vals, g):
+        lower_vals, g = f64(lower_vals), f64(g)
+        x = np.empty_like(g)
+        call("mgb_amg_solve_linear", self.handle, l, dptr(lower_vals), dptr(g), dptr(x))
+        return x
+
+    def solve(self, tol=None, t=0.1, kappa=10.0, maxit=10000, max_newton=0, verbose=0):
+        call("mgb_amg_solve", self.handle, float(tol or 0.0), float(t), float(kappa), int(maxit), int(max_newton),
+             int(verbose))
+        nt, te, tf = C.c_int(), C.c_double(), C.c_double()
+        counts = (C.c_longlong * 4)()
+        call("mgb_amg_sol_info", self.handle, C.byref(nt), C.byref(te), C.byref(tf), counts)
+        its = np.empty(self.L * nt.value, dtype=np.int64)
+        ts = np.empty(nt.value)
+        cd = np.empty(nt.value)
+        call("mgb_amg_sol_get", self.handle, its.ctypes.data_as(_lib.c_ll_p), dptr(ts), dptr(cd))
+        return dict(t_elapsed=te.value, ts=ts, its=its.reshape(nt.value, self.L).T.copy(), c_dot_Dz=cd,
+                    time_factor=tf.value, n_f0=counts[0], n_f1=counts[1], n_f2=counts[2], n_factor=counts[3])
+
+    def time_kernels(self, l, reps=50):
+        ms = np.empty(6)
+        by = np.empty(6)
+        call("mgb_amg_time_kernels", self.handle, l, reps, dptr(ms), dptr(by))
+        names = ("apply_D", "barrier_f2", "hessian_assemble", "barrier_f1", "restrict", "barrier_f0")
+        return {k: dict(ms=float(m), bytes=float(b)) for k, m, b in zip(names, ms, by)}
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().mgb_amg_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def amg(geometry: Geometry, state_variables=DEFAULT_STATE, D=None, p=1.0) -> AMG:
+    return AMG(geometry, state_variables, D, p)
+
+
+@dataclass
+class AMGBSOL:
+    """src:467-473 field order."""
+    z: object
+    SOL_feasibility: Optional[dict]
+    SOL_main: dict
+    log: list
+    geometry: Geometry
+
+
+def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=None, g=None, tol=None, t=0.1,
+         maxit=10000, kappa=10.0, verbose=False, logfile=None, **rest) -> AMGBSOL:
+    """MultiGridBarrier.amgb on an MPI geometry (called at src:599,666).  kwargs as documented in
+    docs/src/guide.md:148-152; unknown kwargs (e.g. `L`, forwarded by fem*d_mpi_solve, src:663-666)
+    are ignored like Julia's `kwargs...` fan-out."""
+    if geometry._geo is None:
+        raise TypeError("amgb: geometry must come from native_to_mpi / fem*d_mpi")
+    dim = geometry.discretization["dim"]
+    f = DEFAULT_F[dim] if f is None else f
+    g = DEFAULT_G[dim] if g is None else g
+    M = AMG(geometry, state_variables, D, p)
+    x = geometry.x.to_numpy()
+    z0 = np.vstack([np.asarray(g(xi), dtype=np.float64) for xi in x])        # g_grid (n, S)
+    c = np.vstack([np.asarray(f(xi), dtype=np.float64) for xi in x])         # f_grid (n, K)
+    M.set_c(c)
+    M.set_z(z0.reshape(-1, order="F"))
+    y0 = M.f0(M.L - 1, np.zeros(M.level_size(M.L - 1)[0]), 0.0)
+    if not math.isfinite(y0):
+        raise NotImplementedError("amgb: the initial point is not strictly feasible; the feasibility phase "
+                                  "(SOL_feasibility) is not built yet (SURVEY §8f-3)")
+    SOL = M.solve(tol=tol, t=t, kappa=kappa, maxit=maxit, verbose=2 if verbose and verbose > 1 else int(bool(verbose)))
+    z = M.get_z().reshape(z0.shape, order="F")
+    return AMGBSOL(HPCMatrix(z, geometry.x.backend), None, SOL, [], geometry)
+
+
+def fem1d_mpi_solve(L: int = 4, **kwargs) -> AMGBSOL:
+    """src:594-600: kwargs go to both fem1d_mpi and amgb."""
+    geo_kw = {k: kwargs[k] for k in ("Ti", "backend") if k in kwargs}
+    return amgb(fem1d_mpi(L, **geo_kw), **{k: v for k, v in kwargs.items() if k not in geo_kw})
+
+
+def fem2d_mpi_solve(L: int = 2, K=None, **kwargs) -> AMGBSOL:
+    """src:661-667."""
+    geo_kw = {k: kwargs[k] for k in ("Ti", "backend") if k in kwargs}
+    return amgb(fem2d_mpi(L, K, **geo_kw), **{k: v for k, v in kwargs.items() if k not in geo_kw})
+
+
+def mpi_to_native(obj):
+    """src:355-517: gather device objects back to native numpy/scipy types."""
+    if isinstance(obj, Geometry):
+        conv = lambda m: m.to_scipy() if isinstance(m, HPCSparseMatrix) else m
+        return Geometry(dict(obj.discretization), _to_cpu_array(obj.x), _to_cpu_array(obj.w),
+                        {k: [conv(m) for m in v] for k, v in obj.subspaces.items()},
+                        {k: conv(m) for k, m in obj.operators.items()},
+                        [conv(m) for m in obj.refine], [conv(m) for m in obj.coarsen])
+    if isinstance(obj, AMGBSOL):
+        return AMGBSOL(_to_cpu_array(obj.z), obj.SOL_feasibility, obj.SOL_main, obj.log, mpi_to_native(obj.geometry))
+    if isinstance(obj, (HPCVector, HPCMatrix)):
+        return obj.to_numpy()
+    if isinstance(obj, HPCSparseMatrix):
+        return obj.to_scipy()
+    return obj

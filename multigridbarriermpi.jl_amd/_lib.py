@@ -1,0 +1,134 @@
+"""ctypes binding of libmgb_hip.so (include/mgb_hip.h).  No torch types cross this boundary."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmgb_hip.so")
+
+c_int_p = C.POINTER(C.c_int)
+c_i32_p = C.POINTER(C.c_int32)
+c_dbl_p = C.POINTER(C.c_double)
+c_ll_p = C.POINTER(C.c_longlong)
+c_str_arr = C.POINTER(C.c_char_p)
+H = C.c_void_p
+
+
+class MGBError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mgb error %d: %s" % (code, msg))
+        self.code = code
+
+
+# name -> argtypes (return type is always int unless listed in _SPECIAL)
+PROTOTYPES = {
+    "mgb_ctx_create": [C.c_int, C.POINTER(H)],
+    "mgb_ctx_destroy": [H],
+    "mgb_ctx_synchronize": [H],
+    "mgb_fem1d_native": [C.c_int, C.POINTER(H)],
+    "mgb_fem2d_native": [C.c_int, c_dbl_p, C.c_int, C.POINTER(H)],
+    "mgb_geo_create": [C.c_int, C.c_int, C.c_int, C.c_int, c_dbl_p, c_dbl_p, C.POINTER(H)],
+    "mgb_geo_set_matrix": [H, C.c_char_p, C.c_int, C.c_int, c_i32_p, c_i32_p, c_dbl_p],
+    "mgb_geo_destroy": [H],
+    "mgb_geo_dims": [H, c_int_p, c_int_p, c_int_p, c_int_p],
+    "mgb_geo_get_xw": [H, c_dbl_p, c_dbl_p],
+    "mgb_geo_matrix_info": [H, C.c_char_p, c_int_p, c_int_p, c_int_p],
+    "mgb_geo_matrix_get": [H, C.c_char_p, c_i32_p, c_i32_p, c_dbl_p],
+    "mgb_vec_create": [H, C.c_int, c_dbl_p, C.POINTER(H)],
+    "mgb_vec_free": [H],
+    "mgb_vec_len": [H, c_int_p],
+    "mgb_vec_upload": [H, c_dbl_p],
+    "mgb_vec_download": [H, c_dbl_p],
+    "mgb_csr_create": [H, C.c_int, C.c_int, c_i32_p, c_i32_p, c_dbl_p, C.POINTER(H)],
+    "mgb_csr_free": [H],
+    "mgb_diag": [H, H, C.c_int, C.c_int, C.POINTER(H)],
+    "mgb_spmv": [H, H, H],
+    "mgb_spmv_add": [H, H, H, H],
+    "mgb_dot": [H, H, c_dbl_p],
+    "mgb_mul": [H, H, H],
+    "mgb_axpy": [H, C.c_double, H, H],
+    "mgb_all_isfinite": [H, c_int_p],
+    "mgb_amg_create": [H, H, C.c_int, c_str_arr, C.c_int, c_str_arr, C.c_int, c_int_p, C.c_int, C.c_double,
+                       C.POINTER(H)],
+    "mgb_amg_destroy": [H],
+    "mgb_amg_dims": [H, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p],
+    "mgb_amg_level_size": [H, C.c_int, c_int_p, c_int_p],
+    "mgb_amg_hessian_pattern": [H, C.c_int, c_i32_p, c_i32_p],
+    "mgb_amg_set_c": [H, c_dbl_p],
+    "mgb_amg_set_z": [H, c_dbl_p],
+    "mgb_amg_get_z": [H, c_dbl_p],
+    "mgb_amg_apply_D": [H, C.c_int, c_dbl_p, c_dbl_p],
+    "mgb_amg_f0": [H, C.c_int, c_dbl_p, C.c_double, c_dbl_p, c_dbl_p],
+    "mgb_amg_f1": [H, C.c_int, c_dbl_p, C.c_double, c_dbl_p],
+    "mgb_amg_f2": [H, C.c_int, c_dbl_p, C.c_double, c_dbl_p],
+    "mgb_amg_solve_linear": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],
+    "mgb_amg_solve": [H, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int],
+    "mgb_amg_sol_info": [H, c_int_p, c_dbl_p, c_dbl_p, c_ll_p],
+    "mgb_amg_sol_get": [H, c_ll_p, c_dbl_p, c_dbl_p],
+    "mgb_amg_time_kernels": [H, C.c_int, C.c_int, c_dbl_p, c_dbl_p],
+    "mgb_plan_create": [H, C.c_int, c_str_arr, C.c_int, c_str_arr, C.c_int, c_int_p, C.c_int, C.c_int,
+                        C.POINTER(H)],
+    "mgb_plan_destroy": [H],
+    "mgb_plan_sizes": [H, c_int_p, c_int_p, c_int_p, c_int_p],
+    "mgb_plan_pattern": [H, c_i32_p, c_i32_p],
+    "mgb_plan_eval_host": [H, c_dbl_p, c_dbl_p],
+    "mgb_chol_selftest": [C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],
+}
+_SPECIAL = {"mgb_last_error": ([], C.c_char_p), "mgb_version": ([], C.c_int), "mgb_device_count": ([], C.c_int)}
+
+_lib = None
+
+
+def load():
+    """Load libmgb_hip.so; fail loudly if it has not been built (there is no Python/CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libmgb_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or multigridbarriermpi.jl_amd/csrc/build.sh (expected at %s)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name, (args, res) in _SPECIAL.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise MGBError(rc, lib.mgb_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(c_dbl_p)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(c_i32_p)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def str_array(pairs):
+    flat = []
+    for a, b in pairs:
+        flat += [str(a).encode(), str(b).encode()]
+    return (C.c_char_p * len(flat))(*flat)

@@ -1,0 +1,571 @@
+#include "amg.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+
+namespace mgb {
+
+void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+Ctx::Ctx(int dev) : device(dev) {
+  int count = 0;
+  hip_check(hipGetDeviceCount(&count), "hipGetDeviceCount");
+  if (count <= 0) throw std::runtime_error("mgb: no HIP device visible (the HIP path has no CPU fallback)");
+  if (dev < 0 || dev >= count) throw std::runtime_error("mgb: device id out of range");
+  hip_check(hipSetDevice(dev), "hipSetDevice");
+  hip_check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+}
+
+Ctx::~Ctx() {
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+static int pick_group(const Csr& A) {
+  if (A.rows == 0) return 1;
+  double avg = (double)A.nnz() / A.rows;
+  int g = 1;
+  while (g < 64 && g < avg) g <<= 1;
+  return g;
+}
+
+void DevCsrOwned::upload(const Csr& A) {
+  rowptr.upload(A.rowptr.data(), A.rowptr.size());
+  colidx.upload(A.colidx.data(), A.colidx.size());
+  vals.upload(A.vals.data(), A.vals.size());
+  view.rows = A.rows;
+  view.cols = A.cols;
+  view.nnz = A.nnz();
+  view.group = pick_group(A);
+  view.rowptr = rowptr.p;
+  view.colidx = colidx.p;
+  view.vals = vals.p;
+}
+
+// ------------------------------------------------------------------ host symbolic setup
+
+static int state_index(const AmgSpec& spec, const std::string& name) {
+  for (size_t i = 0; i < spec.state_variables.size(); ++i)
+    if (spec.state_variables[i].first == name) return (int)i;
+  throw std::runtime_error("amg: D refers to unknown state variable '" + name + "'");
+}
+
+Csr build_dstack(const GeometryHost& g, const AmgSpec& spec) {
+  const int n = g.n, K = (int)spec.D.size(), S = (int)spec.state_variables.size();
+  Csr D(n * K, n * S);
+  std::vector<const Csr*> ops(K);
+  std::vector<int> off(K);
+  for (int k = 0; k < K; ++k) {
+    auto it = g.operators.find(spec.D[k].second);
+    if (it == g.operators.end()) throw std::runtime_error("amg: unknown operator '" + spec.D[k].second + "'");
+    if (it->second.rows != n || it->second.cols != n) throw std::runtime_error("amg: operator is not n x n");
+    ops[k] = &it->second;
+    off[k] = state_index(spec, spec.D[k].first) * n;
+  }
+  for (int q = 0; q < n; ++q)
+    for (int k = 0; k < K; ++k) {
+      const Csr& A = *ops[k];
+      for (int e = A.rowptr[q]; e < A.rowptr[q + 1]; ++e) {
+        D.colidx.push_back(A.colidx[e] + off[k]);
+        D.vals.push_back(A.vals[e]);
+      }
+      D.rowptr[q * K + k + 1] = (int)D.colidx.size();
+    }
+  return D;
+}
+
+LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr& Dstack, int level,
+                           const BarrierParams& P) {
+  LevelPlan pl;
+  const int n = g.n, K = P.K, S = (int)spec.state_variables.size();
+  std::vector<const Csr*> subs;
+  for (auto& sv : spec.state_variables) {
+    auto it = g.subspaces.find(sv.second);
+    if (it == g.subspaces.end()) throw std::runtime_error("amg: unknown subspace '" + sv.second + "'");
+    if (level < 0 || level >= (int)it->second.size()) throw std::runtime_error("amg: level out of range");
+    if (it->second[level].rows != n) throw std::runtime_error("amg: subspace matrix must have n rows");
+    subs.push_back(&it->second[level]);
+  }
+  pl.R = blockdiag(subs);
+  pl.N = pl.R.cols;
+  pl.B = spgemm(Dstack, pl.R);
+  pl.BT = transpose(pl.B);
+  // representative coordinates of the unknowns (ordering quality only)
+  pl.coords.assign((size_t)pl.N * g.dim, 0.0);
+  {
+    std::vector<double> best(pl.N, -1.0);
+    for (int r = 0; r < pl.R.rows; ++r)
+      for (int e = pl.R.rowptr[r]; e < pl.R.rowptr[r + 1]; ++e) {
+        const int cidx = pl.R.colidx[e];
+        const double a = std::fabs(pl.R.vals[e]);
+        if (a > best[cidx]) {
+          best[cidx] = a;
+          for (int d = 0; d < g.dim; ++d) pl.coords[(size_t)cidx * g.dim + d] = g.x[(size_t)(r % n) * g.dim + d];
+        }
+      }
+  }
+  // Hessian plan: A = sum_q sum_{a<=b} Y[q,slot(a,b)] * (B_a[q,:]' B_b[q,:] + sym), lower triangle only
+  const int nact = P.nact(), nY = P.nY();
+  std::vector<int> act(nact);
+  for (int i = 0; i < P.nq; ++i) act[i] = P.iq[i];
+  act[P.nq] = P.is;
+  struct RowU {
+    std::vector<int> cols;
+    std::vector<double> val;     // nact x ncols
+    std::vector<char> present;   // nact x ncols
+  };
+  auto gather = [&](int q, RowU& u) {
+    u.cols.clear();
+    for (int a = 0; a < nact; ++a) {
+      const int r = q * K + act[a];
+      for (int e = pl.B.rowptr[r]; e < pl.B.rowptr[r + 1]; ++e) u.cols.push_back(pl.B.colidx[e]);
+    }
+    std::sort(u.cols.begin(), u.cols.end());
+    u.cols.erase(std::unique(u.cols.begin(), u.cols.end()), u.cols.end());
+    const int nc = (int)u.cols.size();
+    u.val.assign((size_t)nact * nc, 0.0);
+    u.present.assign((size_t)nact * nc, 0);
+    for (int a = 0; a < nact; ++a) {
+      const int r = q * K + act[a];
+      for (int e = pl.B.rowptr[r]; e < pl.B.rowptr[r + 1]; ++e) {
+        const int j = (int)(std::lower_bound(u.cols.begin(), u.cols.end(), pl.B.colidx[e]) - u.cols.begin());
+        u.val[(size_t)a * nc + j] = pl.B.vals[e];
+        u.present[(size_t)a * nc + j] = 1;
+      }
+    }
+  };
+  auto structural = [&](const RowU& u, int nc, int a, int b, int i, int j) {
+    return (u.present[(size_t)a * nc + i] && u.present[(size_t)b * nc + j]) ||
+           (a != b && u.present[(size_t)b * nc + i] && u.present[(size_t)a * nc + j]);
+  };
+  // pass A: pattern
+  std::vector<unsigned long long> keys;
+  keys.reserve((size_t)n * 40);
+  RowU u;
+  for (int q = 0; q < n; ++q) {
+    gather(q, u);
+    const int nc = (int)u.cols.size();
+    for (int i = 0; i < nc; ++i)
+      for (int j = 0; j <= i; ++j) {
+        bool any = false;
+        for (int a = 0; a < nact && !any; ++a)
+          for (int b = a; b < nact && !any; ++b) any = structural(u, nc, a, b, i, j);
+        if (any) keys.push_back(((unsigned long long)u.cols[i] << 32) | (unsigned)u.cols[j]);
+      }
+    if (keys.size() > (size_t)64 << 20) {  // compact periodically
+      std::sort(keys.begin(), keys.end());
+      keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    }
+  }
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  pl.Apat = Csr(pl.N, pl.N);
+  pl.Apat.colidx.resize(keys.size());
+  pl.Apat.vals.assign(keys.size(), 0.0);
+  for (size_t e = 0; e < keys.size(); ++e) {
+    pl.Apat.rowptr[(int)(keys[e] >> 32) + 1]++;
+    pl.Apat.colidx[e] = (int)(keys[e] & 0xffffffffu);
+  }
+  for (int r = 0; r < pl.N; ++r) pl.Apat.rowptr[r + 1] += pl.Apat.rowptr[r];
+  auto entry = [&](int r, int c) {
+    const int* b = pl.Apat.colidx.data() + pl.Apat.rowptr[r];
+    const int* e = pl.Apat.colidx.data() + pl.Apat.rowptr[r + 1];
+    return (int)(std::lower_bound(b, e, c) - pl.Apat.colidx.data());
+  };
+  // pass B: count, pass C: fill (terms of one entry end up ordered by q, then slot)
+  const int nnzA = pl.Apat.nnz();
+  pl.T = Csr(nnzA, n * nY);
+  std::vector<long long> cnt(nnzA + 1, 0);
+  for (int pass = 0; pass < 2; ++pass) {
+    std::vector<long long> pos;
+    if (pass == 1) {
+      long long tot = 0;
+      for (int e = 0; e < nnzA; ++e) {
+        long long c0 = cnt[e];
+        cnt[e] = tot;
+        tot += c0;
+      }
+      cnt[nnzA] = tot;
+      if (tot > 2000000000LL) throw std::runtime_error("amg: Hessian plan exceeds Int32 indexing");
+      for (int e = 0; e <= nnzA; ++e) pl.T.rowptr[e] = (int)cnt[e];
+      pl.T.colidx.resize((size_t)tot);
+      pl.T.vals.resize((size_t)tot);
+      pos.assign(cnt.begin(), cnt.end() - 1);
+    }
+    for (int q = 0; q < n; ++q) {
+      gather(q, u);
+      const int nc = (int)u.cols.size();
+      for (int i = 0; i < nc; ++i)
+        for (int j = 0; j <= i; ++j) {
+          int e = -1;
+          int slot = 0;
+          for (int a = 0; a < nact; ++a)
+            for (int b = a; b < nact; ++b, ++slot) {
+              if (!structural(u, nc, a, b, i, j)) continue;
+              if (e < 0) e = entry(u.cols[i], u.cols[j]);
+              if (pass == 0) {
+                cnt[e]++;
+              } else {
+                double coef = u.val[(size_t)a * nc + i] * u.val[(size_t)b * nc + j];
+                if (a != b) coef += u.val[(size_t)b * nc + i] * u.val[(size_t)a * nc + j];
+                const long long p = pos[e]++;
+                pl.T.colidx[p] = q * nY + slot;
+                pl.T.vals[p] = coef;
+              }
+            }
+        }
+    }
+  }
+  return pl;
+}
+
+// ------------------------------------------------------------------ Amg
+
+Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierParams& P)
+    : ctx_(ctx), n_(g.n), S_((int)spec.state_variables.size()), P_(P), spec_(spec) {
+  hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
+  if (P.K != (int)spec.D.size()) throw std::runtime_error("amg: barrier K != number of D rows");
+  if (P.nq < 1 || P.nq > 3) throw std::runtime_error("amg: barrier supports 1..3 gradient components");
+  for (int i = 0; i < P.nq; ++i)
+    if (P.iq[i] < 0 || P.iq[i] >= P.K) throw std::runtime_error("amg: barrier index out of range");
+  if (P.is < 0 || P.is >= P.K) throw std::runtime_error("amg: barrier index out of range");
+  if ((int)g.w.size() != n_ || (int)g.x.size() != n_ * g.dim) throw std::runtime_error("amg: geometry x/w size mismatch");
+  Csr Dstack = build_dstack(g, spec);
+  Dstack_.upload(Dstack);
+  w_.upload(g.w.data(), n_);
+  w_min_ = *std::min_element(g.w.begin(), g.w.end());
+  const int K = P.K, nY = P.nY();
+  c_.alloc((size_t)n_ * K);
+  z_.alloc((size_t)n_ * S_);
+  z_save_.alloc((size_t)n_ * S_);
+  Dz0_.alloc((size_t)n_ * K);
+  Dz_.alloc((size_t)n_ * K);
+  v_.alloc((size_t)n_ * K);
+  Y_.alloc((size_t)n_ * nY);
+  partials_.alloc((size_t)2 * f0_blocks(n_) + 16);
+  scal_.alloc(8);
+  h_scal_.alloc(8);
+  hip_check(hipMemset(c_.p, 0, c_.n * sizeof(double)), "memset");
+  hip_check(hipMemset(z_.p, 0, z_.n * sizeof(double)), "memset");
+  const int L = g.L;
+  for (int l = 0; l < L; ++l) {
+    levels_.emplace_back(new Level);
+    Level& lv = *levels_[l];
+    lv.plan = build_level_plan(g, spec, Dstack, l, P);
+    lv.R.upload(lv.plan.R);
+    lv.B.upload(lv.plan.B);
+    lv.BT.upload(lv.plan.BT);
+    lv.T.upload(lv.plan.T);
+    lv.chol.analyze(lv.plan.Apat, lv.plan.coords.data(), g.dim);
+    const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
+    lv.s.alloc(N);
+    lv.s_trial.alloc(N);
+    lv.g.alloc(N);
+    lv.nstep.alloc(N);
+    lv.avals.alloc(nnzA);
+    lv.h_avals.alloc(nnzA);
+    lv.h_g.alloc(N);
+    lv.h_n.alloc(N);
+    lv.h_s.alloc(N);
+  }
+}
+
+void Amg::set_c(const double* c_host) { c_.upload(c_host, (size_t)n_ * P_.K); }
+
+void Amg::set_z(const double* z_host) {
+  z_.upload(z_host, (size_t)n_ * S_);
+  refresh_dz0();
+}
+
+void Amg::get_z(double* z_host) {
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync");
+  z_.download(z_host, (size_t)n_ * S_);
+}
+
+void Amg::refresh_dz0() { launch_spmv(ctx_.stream, Dstack_.view, z_.p, nullptr, Dz0_.p); }
+
+void Amg::dev_apply(Level& lv, const double* s_dev) { launch_spmv(ctx_.stream, lv.B.view, s_dev, Dz0_.p, Dz_.p); }
+
+double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts) {
+  dev_apply(lv, s_dev);
+  launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, partials_.p, scal_.p);
+  hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync f0");
+  if (parts) {
+    parts[0] = h_scal_.p[0];
+    parts[1] = h_scal_.p[1];
+  }
+  return h_scal_.p[0] + t * h_scal_.p[1];
+}
+
+void Amg::dev_f1(Level& lv, const double* s_dev, double t, bool reuse_dz) {
+  if (!reuse_dz) dev_apply(lv, s_dev);
+  launch_barrier_f1(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, t, v_.p);
+  launch_spmv(ctx_.stream, lv.BT.view, v_.p, nullptr, lv.g.p);
+  hip_check(hipMemcpyAsync(lv.h_g.p, lv.g.p, (size_t)lv.plan.N * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
+            "D2H g");
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync f1");
+}
+
+bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st) {
+  (void)t;
+  const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
+  dev_apply(lv, s_dev);
+  launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p);
+  launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
+  hip_check(hipMemcpyAsync(lv.h_avals.p, lv.avals.p, (size_t)nnzA * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
+            "D2H avals");
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync f2");
+  st.n_f2++;
+  const double t0 = now_s();
+  bool ok = lv.chol.factor(lv.h_avals.p);
+  if (ok) {
+    std::copy(lv.h_g.p, lv.h_g.p + N, lv.h_n.p);
+    lv.chol.solve(lv.h_n.p);
+  }
+  st.time_factor += now_s() - t0;
+  st.n_factor++;
+  return ok;
+}
+
+static const double kBeta = 0.5, kArmijo = 0.1, kMinStep = 1e-8;
+
+Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int maxit, SolveStats& st, int verbose) {
+  Level& lv = *levels_[l];
+  const int N = lv.plan.N;
+  NewtonResult res;
+  if (N == 0) {
+    res.converged = true;
+    return res;
+  }
+  hip_check(hipMemsetAsync(lv.s.p, 0, (size_t)N * sizeof(double), ctx_.stream), "memset s");
+  double y = dev_f0(lv, lv.s.p, t, nullptr);
+  st.n_f0++;
+  if (!std::isfinite(y)) throw std::runtime_error("newton: infeasible start");
+  dev_f1(lv, lv.s.p, t, true);
+  st.n_f1++;
+  auto norm2 = [&](const double* a) {
+    double s2 = 0;
+    for (int i = 0; i < N; ++i) s2 += a[i] * a[i];
+    return std::sqrt(s2);
+  };
+  double gnorm = norm2(lv.h_g.p);
+  double ymin = y, gmin = gnorm, incmin = INFINITY;
+  const double theta = finest ? 0.1 : 0.5;
+  while (res.k < maxit && !res.converged) {
+    res.k++;
+    if (!dev_f2_solve(lv, lv.s.p, t, st)) break;
+    double inc = 0;
+    bool fin = true;
+    for (int i = 0; i < N; ++i) {
+      inc += lv.h_g.p[i] * lv.h_n.p[i];
+      fin = fin && std::isfinite(lv.h_n.p[i]);
+    }
+    if (!fin) break;
+    if (inc <= 0) {
+      res.converged = true;
+      break;
+    }
+    hip_check(hipMemcpyAsync(lv.nstep.p, lv.h_n.p, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx_.stream),
+              "H2D n");
+    // backtracking line search: trial must be finite (amgb_all_isfinite, src:121) and satisfy Armijo
+    double step = 1.0, ynext = y, gnext = gnorm;
+    bool accepted = false;
+    while (step >= kMinStep) {
+      launch_waxpby(ctx_.stream, N, lv.s.p, -step, lv.nstep.p, lv.s_trial.p);
+      const double yt = dev_f0(lv, lv.s_trial.p, t, nullptr);
+      st.n_f0++;
+      if (std::isfinite(yt) && yt <= y - kArmijo * step * inc) {
+        std::copy(lv.h_g.p, lv.h_g.p + N, lv.h_s.p);  // keep old gradient in case the new one is not finite
+        dev_f1(lv, lv.s_trial.p, t, true);
+        st.n_f1++;
+        bool gfin = true;
+        for (int i = 0; i < N; ++i) gfin = gfin && std::isfinite(lv.h_g.p[i]);
+        if (gfin) {
+          ynext = yt;
+          gnext = norm2(lv.h_g.p);
+          accepted = true;
+          break;
+        }
+        std::copy(lv.h_s.p, lv.h_s.p + N, lv.h_g.p);
+      }
+      step *= kBeta;
+    }
+    if (accepted) std::swap(lv.s.p, lv.s_trial.p);
+    if (!accepted) step = 0.0;
+    const bool exact = ynext >= ymin && gnext >= theta * gmin;
+    if ((!finest && inc < lam_tol) || exact) res.converged = true;
+    y = ynext;
+    gnorm = gnext;
+    ymin = std::min(ymin, y);
+    gmin = std::min(gmin, gnorm);
+    incmin = std::min(incmin, inc);
+    if (verbose > 1)
+      fprintf(stderr, "    [mgb] level %d k=%d y=%.12g |g|=%.3g inc=%.3g step=%.3g\n", l, res.k, y, gnorm, inc, step);
+  }
+  return res;
+}
+
+bool Amg::amgb_step(double t, double lam_tol, int max_newton, std::vector<long long>& its, SolveStats& st, int verbose) {
+  const int L = (int)levels_.size();
+  bool converged = true;
+  for (int J = 0; J < L; ++J) {
+    Level& lv = *levels_[J];
+    NewtonResult r = newton(J, t, J == L - 1, lam_tol, max_newton, st, verbose);
+    its[J] += r.k;
+    if (lv.plan.N > 0) {
+      launch_spmv(ctx_.stream, lv.R.view, lv.s.p, z_.p, z_.p);
+      refresh_dz0();
+    }
+    if (J == L - 1) converged = r.converged;
+  }
+  return converged;
+}
+
+double Amg::c_dot_dz() {
+  launch_barrier_f0(ctx_.stream, n_, P_, Dz0_.p, w_.p, c_.p, partials_.p, scal_.p);
+  hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync");
+  return h_scal_.p[1];
+}
+
+void Amg::solve(const SolveOptions& opt, SolveStats& st) {
+  hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
+  const int L = (int)levels_.size();
+  st = SolveStats();
+  st.L = L;
+  const double t_begin = now_s();
+  const double lam_tol = std::sqrt(w_min_) / 2;
+  double t = opt.t0, kappa = opt.kappa;
+  const double kappa0 = opt.kappa;
+  const size_t zbytes = (size_t)n_ * S_ * sizeof(double);
+  std::vector<long long> its(L, 0);
+  refresh_dz0();
+  if (!amgb_step(t, lam_tol, opt.max_newton, its, st, opt.verbose))
+    throw std::runtime_error("amgb: initial centering failed");
+  st.its.insert(st.its.end(), its.begin(), its.end());
+  st.ts.push_back(t);
+  st.c_dot_Dz.push_back(c_dot_dz());
+  int k = 1;
+  while (t <= 1 / opt.tol && kappa > 1 && k < opt.maxit) {
+    k++;
+    std::fill(its.begin(), its.end(), 0);
+    while (kappa > 1) {
+      const double t1 = kappa * t;
+      hip_check(hipMemcpyAsync(z_save_.p, z_.p, zbytes, hipMemcpyDeviceToDevice, ctx_.stream), "save z");
+      std::vector<long long> it1(L, 0);
+      bool ok = amgb_step(t1, lam_tol, opt.max_newton, it1, st, opt.verbose);
+      long long mx = 0;
+      for (int l = 0; l < L; ++l) {
+        its[l] += it1[l];
+        mx = std::max(mx, it1[l]);
+      }
+      if (ok) {
+        if (mx <= opt.max_newton * 0.5) kappa = std::min(kappa0, kappa * kappa);
+        t = t1;
+        break;
+      }
+      hip_check(hipMemcpyAsync(z_.p, z_save_.p, zbytes, hipMemcpyDeviceToDevice, ctx_.stream), "restore z");
+      refresh_dz0();
+      kappa = std::sqrt(kappa);
+      if (kappa < 1 + 1e-3) kappa = 1.0;
+    }
+    st.its.insert(st.its.end(), its.begin(), its.end());
+    st.ts.push_back(t);
+    st.c_dot_Dz.push_back(c_dot_dz());
+    if (opt.verbose)
+      fprintf(stderr, "[mgb] t=%.4g kappa=%.3g its(finest)=%lld c.Dz=%.12g\n", t, kappa, its[L - 1], st.c_dot_Dz.back());
+  }
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync");
+  st.t_elapsed = now_s() - t_begin;
+  if (t <= 1 / opt.tol) throw std::runtime_error("amgb: convergence failure (kappa collapsed)");
+}
+
+// ------------------------------------------------------------------ fine-grained entry points
+
+double Amg::f0(int l, const double* s_host, double t, double* parts) {
+  Level& lv = *levels_.at(l);
+  lv.s_trial.upload(s_host, lv.plan.N);
+  return dev_f0(lv, lv.s_trial.p, t, parts);
+}
+
+void Amg::f1(int l, const double* s_host, double t, double* g_host) {
+  Level& lv = *levels_.at(l);
+  lv.s_trial.upload(s_host, lv.plan.N);
+  dev_f1(lv, lv.s_trial.p, t, false);
+  std::copy(lv.h_g.p, lv.h_g.p + lv.plan.N, g_host);
+}
+
+void Amg::f2(int l, const double* s_host, double t, double* avals_host) {
+  (void)t;
+  Level& lv = *levels_.at(l);
+  lv.s_trial.upload(s_host, lv.plan.N);
+  dev_apply(lv, lv.s_trial.p);
+  launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p);
+  launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync f2");
+  lv.avals.download(avals_host, lv.plan.Apat.nnz());
+}
+
+void Amg::apply_D(int l, const double* s_host, double* Dz_host) {
+  Level& lv = *levels_.at(l);
+  lv.s_trial.upload(s_host, lv.plan.N);
+  dev_apply(lv, lv.s_trial.p);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync");
+  Dz_.download(Dz_host, (size_t)n_ * P_.K);
+}
+
+bool Amg::solve_host(int l, const double* avals, const double* g, double* nstep) {
+  Level& lv = *levels_.at(l);
+  if (!lv.chol.factor(avals)) return false;
+  std::copy(g, g + lv.plan.N, nstep);
+  lv.chol.solve(nstep);
+  return true;
+}
+
+static double csr_bytes(const DevCsr& A, bool y0) {
+  return (double)A.nnz * 12.0 + (A.rows + 1) * 4.0 + A.cols * 8.0 + A.rows * 8.0 * (y0 ? 2 : 1);
+}
+
+Amg::KernelTimes Amg::time_kernels(int l, int reps) {
+  Level& lv = *levels_.at(l);
+  KernelTimes kt{};
+  hipEvent_t e0, e1;
+  hip_check(hipEventCreate(&e0), "event");
+  hip_check(hipEventCreate(&e1), "event");
+  hip_check(hipMemsetAsync(lv.s.p, 0, (size_t)lv.plan.N * sizeof(double), ctx_.stream), "memset");
+  auto timeit = [&](auto&& fn) {
+    fn();  // warm
+    hip_check(hipEventRecord(e0, ctx_.stream), "rec");
+    for (int r = 0; r < reps; ++r) fn();
+    hip_check(hipEventRecord(e1, ctx_.stream), "rec");
+    hip_check(hipEventSynchronize(e1), "evsync");
+    float ms = 0;
+    hip_check(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+    return (double)ms / reps;
+  };
+  const double n = n_, K = P_.K, nY = P_.nY();
+  kt.apply_ms = timeit([&] { dev_apply(lv, lv.s.p); });
+  kt.apply_bytes = csr_bytes(lv.B.view, true);
+  kt.f2_ms = timeit([&] { launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p); });
+  kt.f2_bytes = n * (K + 1 + nY) * 8;
+  kt.assemble_ms = timeit([&] { launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p); });
+  kt.assemble_bytes = csr_bytes(lv.T.view, false);
+  kt.f1_ms = timeit([&] { launch_barrier_f1(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, 1.0, v_.p); });
+  kt.f1_bytes = n * (3 * K + 1) * 8;
+  kt.restrict_ms = timeit([&] { launch_spmv(ctx_.stream, lv.BT.view, v_.p, nullptr, lv.g.p); });
+  kt.restrict_bytes = csr_bytes(lv.BT.view, false);
+  kt.f0_ms = timeit([&] { launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, partials_.p, scal_.p); });
+  kt.f0_bytes = n * (2 * K + 1) * 8;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return kt;
+}
+
+}  // namespace mgb

@@ -1,0 +1,194 @@
+// AMG hierarchy + barrier Newton path on one MI355X.
+//
+// Reference counterparts (all in the absent MultiGridBarrier.jl, evidenced by the reference's tests):
+//   amg / AMG            R[l] = blockdiag(subspaces[sv][l]), D[k] = hcat(Z.., op, ..Z)
+//                        test/test_d0_construction.jl:82-100
+//   barrier f0/f1/f2     test/test_apply_d.jl:44, test/test_column_extract.jl:50-80,
+//                        test/test_map_rows_compare.jl:102-123,165-170
+//   newton / amgb_step / amgb_core / amgb
+//                        SURVEY.md §3.1; solve hook test/test_instrumented_solve.jl:25-99
+// Device data layout (HBM, per AMG):
+//   Dz, c, v : n x K row-major ;  Y : n x nY row-major ;  z : S*n (column-major n x S, = Julia vec)
+//   per level l:  B_l = Dstack*R_l as CSR with rows q*K+k  (Dz = Dz0 + B_l s: ONE SpMV for apply_D)
+//                 BT_l = B_l' (gather-form restriction: g = BT_l v, no atomics)
+//                 T_l  : (lower-triangle nnz of R_l'HR_l) x (n*nY) plan, A_vals = T_l vec(Y)
+#pragma once
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "geometry.hpp"
+#include "kernels.hpp"
+#include "mfchol.hpp"
+
+namespace mgb {
+
+void hip_check(hipError_t e, const char* what);
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  explicit Ctx(int dev);
+  ~Ctx();
+};
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    if (count) hip_check(hipMalloc((void**)&p, count * sizeof(T)), "hipMalloc");
+  }
+  void upload(const T* h, size_t count) {
+    if (count > n) alloc(count);
+    if (count) hip_check(hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice), "H2D");
+  }
+  void download(T* h, size_t count) const {
+    if (count) hip_check(hipMemcpy(h, p, count * sizeof(T), hipMemcpyDeviceToHost), "D2H");
+  }
+};
+
+template <class T>
+struct PinnedBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  ~PinnedBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+  void alloc(size_t count) {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = count;
+    if (count) hip_check(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault), "hipHostMalloc");
+  }
+};
+
+// Owning device CSR
+struct DevCsrOwned {
+  DevCsr view;
+  DevBuf<int> rowptr, colidx;
+  DevBuf<double> vals;
+  void upload(const Csr& A);
+};
+
+struct AmgSpec {
+  std::vector<std::pair<std::string, std::string>> state_variables;  // (name, subspace key)
+  std::vector<std::pair<std::string, std::string>> D;                // (state var, operator key)
+};
+
+// Host-only symbolic products of one level (testable without a GPU)
+struct LevelPlan {
+  int N = 0;
+  Csr R;        // (S n) x N
+  Csr B;        // (n K) x N, row q*K+k
+  Csr BT;       // N x (n K)
+  Csr Apat;     // N x N lower-triangle pattern of R'HR (vals unused)
+  Csr T;        // nnz(Apat) x (n nY)
+  std::vector<double> coords;  // N x dim
+};
+
+Csr build_dstack(const GeometryHost& g, const AmgSpec& spec);
+LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr& Dstack, int level,
+                           const BarrierParams& P);
+
+struct SolveOptions {
+  double tol = 1.4901161193847656e-08;  // sqrt(eps)
+  double t0 = 0.1;
+  double kappa = 10.0;
+  int maxit = 10000;
+  int max_newton = 48;
+  int verbose = 0;
+};
+
+struct SolveStats {
+  int L = 0;
+  std::vector<long long> its;     // L x nt, column-major (its[l + L*k])
+  std::vector<double> ts, c_dot_Dz;
+  double t_elapsed = 0, t_setup = 0;
+  double time_factor = 0, time_device = 0;
+  long long n_factor = 0, n_f0 = 0, n_f1 = 0, n_f2 = 0;
+};
+
+class Amg {
+ public:
+  Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierParams& P);
+  int n() const { return n_; }
+  int S() const { return S_; }
+  int K() const { return P_.K; }
+  int L() const { return (int)levels_.size(); }
+  int level_size(int l) const { return levels_[l]->plan.N; }
+  const LevelPlan& plan(int l) const { return levels_[l]->plan; }
+  const BarrierParams& params() const { return P_; }
+
+  // problem data: c is n x K row-major, z is the S*n vector [u; s]
+  void set_c(const double* c_host);
+  void set_z(const double* z_host);
+  void get_z(double* z_host);
+
+  // fine-grained evaluations at level l, s (N_l host values), barrier parameter t
+  //   f0 -> returns objective, also fills parts[2] = {sum w F, sum w c.Dz}
+  double f0(int l, const double* s_host, double t, double* parts);
+  void f1(int l, const double* s_host, double t, double* g_host);
+  void f2(int l, const double* s_host, double t, double* avals_host);   // lower-triangle values, plan(l).Apat order
+  void apply_D(int l, const double* s_host, double* Dz_host);          // n x K row-major
+  // solve (R'HR) nstep = g with the level's multifrontal factorization; returns false if not SPD
+  bool solve_host(int l, const double* avals, const double* g, double* nstep);
+
+  // full multigrid-barrier solve from the current z; z updated in place
+  void solve(const SolveOptions& opt, SolveStats& st);
+
+  // raw pieces for benchmarking: run the device part of one F2 evaluation `reps` times
+  struct KernelTimes {
+    double apply_ms, f2_ms, assemble_ms, f1_ms, restrict_ms, f0_ms;
+    double apply_bytes, f2_bytes, assemble_bytes, f1_bytes, restrict_bytes, f0_bytes;
+  };
+  KernelTimes time_kernels(int l, int reps);
+
+ private:
+  struct Level {
+    LevelPlan plan;
+    DevCsrOwned R, B, BT, T;
+    MfChol chol;
+    DevBuf<double> s, s_trial, g, nstep, avals;
+    PinnedBuf<double> h_avals, h_g, h_n, h_s;
+  };
+  struct NewtonResult {
+    int k = 0;
+    bool converged = false;
+  };
+  void refresh_dz0();
+  void dev_apply(Level& lv, const double* s_dev);                 // Dz = Dz0 + B s
+  double dev_f0(Level& lv, const double* s_dev, double t, double* parts);
+  void dev_f1(Level& lv, const double* s_dev, double t, bool reuse_dz);   // -> lv.g and lv.h_g
+  bool dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st);  // -> lv.h_n / lv.nstep
+  NewtonResult newton(int l, double t, bool finest, double lam_tol, int maxit, SolveStats& st, int verbose);
+  bool amgb_step(double t, double lam_tol, int max_newton, std::vector<long long>& its, SolveStats& st, int verbose);
+  double c_dot_dz();
+
+  Ctx& ctx_;
+  int n_ = 0, S_ = 0;
+  BarrierParams P_;
+  AmgSpec spec_;
+  DevCsrOwned Dstack_;
+  std::vector<std::unique_ptr<Level>> levels_;
+  DevBuf<double> w_, c_, z_, z_save_, Dz0_, Dz_, v_, Y_, partials_, scal_;
+  PinnedBuf<double> h_scal_;
+  double w_min_ = 0;
+};
+
+}  // namespace mgb

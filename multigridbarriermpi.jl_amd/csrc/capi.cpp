@@ -1,0 +1,637 @@
+// C ABI of libmgb_hip.so (include/mgb_hip.h): exception firewall + handle plumbing.
+#include "../../include/mgb_hip.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <string>
+
+#include "amg.hpp"
+
+using namespace mgb;
+
+struct mgb_ctx_s {
+  Ctx ctx;
+  explicit mgb_ctx_s(int dev) : ctx(dev) {}
+};
+struct mgb_geo_s {
+  GeometryHost g;
+};
+struct mgb_vec_s {
+  mgb_ctx_s* ctx;
+  DevBuf<double> buf;
+  int n;
+};
+struct mgb_csr_s {
+  mgb_ctx_s* ctx;
+  DevCsrOwned A;
+};
+struct mgb_amg_s {
+  mgb_ctx_s* ctx;
+  std::unique_ptr<Amg> amg;
+  SolveStats stats;
+};
+struct mgb_plan_s {
+  LevelPlan plan;
+  int n, nY;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+template <class F>
+int guard(F&& fn) {
+  try {
+    fn();
+    return MGB_OK;
+  } catch (const std::invalid_argument& e) {
+    return fail(MGB_E_ARG, e.what());
+  } catch (const std::out_of_range& e) {
+    return fail(MGB_E_ARG, e.what());
+  } catch (const std::runtime_error& e) {
+    const std::string m = e.what();
+    int code = MGB_E_INTERNAL;
+    if (m.find("HIP") != std::string::npos || m.find("no HIP device") != std::string::npos) code = MGB_E_HIP;
+    else if (m.rfind("amg:", 0) == 0 || m.rfind("fem", 0) == 0 || m.find("CSR") != std::string::npos || m.rfind("hcat", 0) == 0) code = MGB_E_ARG;
+    else if (m.rfind("amgb:", 0) == 0 || m.rfind("newton:", 0) == 0 || m.rfind("MfChol", 0) == 0) code = MGB_E_NUMERIC;
+    return fail(code, m);
+  } catch (const std::exception& e) {
+    return fail(MGB_E_INTERNAL, e.what());
+  } catch (...) {
+    return fail(MGB_E_INTERNAL, "unknown exception");
+  }
+}
+
+void need(bool cond, const char* msg) {
+  if (!cond) throw std::invalid_argument(msg);
+}
+
+Csr make_csr(int rows, int cols, const int32_t* rowptr, const int32_t* colidx, const double* vals, const char* what) {
+  need(rows >= 0 && cols >= 0 && rowptr, "CSR: null rowptr or negative size");
+  Csr A(rows, cols);
+  A.rowptr.assign(rowptr, rowptr + rows + 1);
+  const int nnz = rowptr[rows];
+  need(nnz >= 0 && (nnz == 0 || (colidx && vals)), "CSR: null colidx/vals");
+  A.colidx.assign(colidx, colidx + nnz);
+  A.vals.assign(vals, vals + nnz);
+  check_csr(A, what);
+  return A;
+}
+
+// "sub:dirichlet:2" -> parts
+std::vector<std::string> split(const std::string& s) {
+  std::vector<std::string> out;
+  size_t p = 0;
+  for (;;) {
+    size_t q = s.find(':', p);
+    out.push_back(s.substr(p, q == std::string::npos ? q : q - p));
+    if (q == std::string::npos) break;
+    p = q + 1;
+  }
+  return out;
+}
+
+Csr* find_matrix(GeometryHost& g, const std::string& name, bool create) {
+  auto parts = split(name);
+  if (parts.size() == 2 && parts[0] == "op") {
+    if (create) return &g.operators[parts[1]];
+    auto it = g.operators.find(parts[1]);
+    return it == g.operators.end() ? nullptr : &it->second;
+  }
+  if (parts.size() == 3 && parts[0] == "sub") {
+    int l = atoi(parts[2].c_str());
+    if (l < 0 || l >= g.L) return nullptr;
+    if (create) {
+      auto& v = g.subspaces[parts[1]];
+      if ((int)v.size() < g.L) v.resize(g.L);
+      return &v[l];
+    }
+    auto it = g.subspaces.find(parts[1]);
+    if (it == g.subspaces.end() || l >= (int)it->second.size()) return nullptr;
+    return &it->second[l];
+  }
+  if (parts.size() == 2 && (parts[0] == "refine" || parts[0] == "coarsen")) {
+    int l = atoi(parts[1].c_str());
+    if (l < 0 || l >= g.L) return nullptr;
+    auto& v = parts[0] == "refine" ? g.refine : g.coarsen;
+    if (create && (int)v.size() < g.L) v.resize(g.L);
+    if (l >= (int)v.size()) return nullptr;
+    return &v[l];
+  }
+  return nullptr;
+}
+
+AmgSpec make_spec(int S, const char* const* sv, int K, const char* const* D) {
+  need(S >= 1 && K >= 1 && sv && D, "amg: empty state_variables or D");
+  AmgSpec spec;
+  for (int i = 0; i < S; ++i) {
+    need(sv[2 * i] && sv[2 * i + 1], "amg: null string");
+    spec.state_variables.emplace_back(sv[2 * i], sv[2 * i + 1]);
+  }
+  for (int k = 0; k < K; ++k) {
+    need(D[2 * k] && D[2 * k + 1], "amg: null string");
+    spec.D.emplace_back(D[2 * k], D[2 * k + 1]);
+  }
+  return spec;
+}
+
+BarrierParams make_params(int K, int nq, const int* idx_q, int idx_s, double p) {
+  need(nq >= 1 && nq <= 3 && idx_q, "barrier: nq must be 1..3");
+  need(p >= 1.0 && std::isfinite(p), "barrier: p must be >= 1");
+  BarrierParams P;
+  P.K = K;
+  P.nq = nq;
+  for (int i = 0; i < nq; ++i) {
+    need(idx_q[i] >= 0 && idx_q[i] < K, "barrier: idx_q out of range");
+    P.iq[i] = idx_q[i];
+  }
+  need(idx_s >= 0 && idx_s < K, "barrier: idx_s out of range");
+  P.is = idx_s;
+  P.a = 2.0 / p;
+  P.mu = (p == 2.0) ? 0.0 : (p < 2.0 ? 1.0 : 2.0);
+  return P;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mgb_last_error(void) { return g_err.c_str(); }
+int mgb_version(void) { return 100; }
+int mgb_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+int mgb_ctx_create(int device_id, mgb_ctx* out) {
+  return guard([&] {
+    need(out, "null out");
+    *out = new mgb_ctx_s(device_id);
+  });
+}
+int mgb_ctx_destroy(mgb_ctx ctx) {
+  return guard([&] { delete ctx; });
+}
+int mgb_ctx_synchronize(mgb_ctx ctx) {
+  return guard([&] {
+    need(ctx, "null ctx");
+    hip_check(hipStreamSynchronize(ctx->ctx.stream), "sync");
+  });
+}
+
+int mgb_fem1d_native(int L, mgb_geo* out) {
+  return guard([&] {
+    need(out, "null out");
+    auto* g = new mgb_geo_s;
+    try {
+      g->g = fem1d_native(L);
+    } catch (...) {
+      delete g;
+      throw;
+    }
+    *out = g;
+  });
+}
+int mgb_fem2d_native(int L, const double* K, int nK_rows, mgb_geo* out) {
+  return guard([&] {
+    need(out, "null out");
+    auto* g = new mgb_geo_s;
+    try {
+      g->g = fem2d_native(L, K, nK_rows);
+    } catch (...) {
+      delete g;
+      throw;
+    }
+    *out = g;
+  });
+}
+int mgb_geo_create(int n, int dim, int L, int block, const double* x, const double* w, mgb_geo* out) {
+  return guard([&] {
+    need(out && x && w && n > 0 && dim >= 1 && dim <= 3 && L >= 1 && block >= 1, "geo_create: bad arguments");
+    auto* g = new mgb_geo_s;
+    g->g.n = n;
+    g->g.dim = dim;
+    g->g.L = L;
+    g->g.block = block;
+    g->g.x.assign(x, x + (size_t)n * dim);
+    g->g.w.assign(w, w + n);
+    *out = g;
+  });
+}
+int mgb_geo_set_matrix(mgb_geo g, const char* name, int rows, int cols, const int32_t* rowptr, const int32_t* colidx,
+                       const double* vals) {
+  return guard([&] {
+    need(g && name, "null argument");
+    Csr A = make_csr(rows, cols, rowptr, colidx, vals, name);
+    Csr* dst = find_matrix(g->g, name, true);
+    need(dst != nullptr, "geo_set_matrix: unknown matrix name");
+    *dst = std::move(A);
+  });
+}
+int mgb_geo_destroy(mgb_geo g) {
+  return guard([&] { delete g; });
+}
+int mgb_geo_dims(mgb_geo g, int* n, int* dim, int* L, int* block) {
+  return guard([&] {
+    need(g, "null geo");
+    if (n) *n = g->g.n;
+    if (dim) *dim = g->g.dim;
+    if (L) *L = g->g.L;
+    if (block) *block = g->g.block;
+  });
+}
+int mgb_geo_get_xw(mgb_geo g, double* x, double* w) {
+  return guard([&] {
+    need(g, "null geo");
+    if (x) std::copy(g->g.x.begin(), g->g.x.end(), x);
+    if (w) std::copy(g->g.w.begin(), g->g.w.end(), w);
+  });
+}
+int mgb_geo_matrix_info(mgb_geo g, const char* name, int* rows, int* cols, int* nnz) {
+  return guard([&] {
+    need(g && name, "null argument");
+    Csr* A = find_matrix(g->g, name, false);
+    need(A != nullptr, "geo_matrix_info: unknown matrix name");
+    if (rows) *rows = A->rows;
+    if (cols) *cols = A->cols;
+    if (nnz) *nnz = A->nnz();
+  });
+}
+int mgb_geo_matrix_get(mgb_geo g, const char* name, int32_t* rowptr, int32_t* colidx, double* vals) {
+  return guard([&] {
+    need(g && name, "null argument");
+    Csr* A = find_matrix(g->g, name, false);
+    need(A != nullptr, "geo_matrix_get: unknown matrix name");
+    if (rowptr) std::copy(A->rowptr.begin(), A->rowptr.end(), rowptr);
+    if (colidx) std::copy(A->colidx.begin(), A->colidx.end(), colidx);
+    if (vals) std::copy(A->vals.begin(), A->vals.end(), vals);
+  });
+}
+
+// ---- device vectors / matrices
+int mgb_vec_create(mgb_ctx ctx, int n, const double* host, mgb_vec* out) {
+  return guard([&] {
+    need(ctx && out && n >= 0, "vec_create: bad arguments");
+    hip_check(hipSetDevice(ctx->ctx.device), "hipSetDevice");
+    auto* v = new mgb_vec_s{ctx, {}, n};
+    try {
+      v->buf.alloc(n);
+      if (host) v->buf.upload(host, n);
+      else if (n) hip_check(hipMemset(v->buf.p, 0, (size_t)n * sizeof(double)), "memset");
+    } catch (...) {
+      delete v;
+      throw;
+    }
+    *out = v;
+  });
+}
+int mgb_vec_free(mgb_vec v) {
+  return guard([&] { delete v; });
+}
+int mgb_vec_len(mgb_vec v, int* n) {
+  return guard([&] {
+    need(v && n, "null argument");
+    *n = v->n;
+  });
+}
+int mgb_vec_upload(mgb_vec v, const double* host) {
+  return guard([&] {
+    need(v && host, "null argument");
+    hip_check(hipStreamSynchronize(v->ctx->ctx.stream), "sync");
+    v->buf.upload(host, v->n);
+  });
+}
+int mgb_vec_download(mgb_vec v, double* host) {
+  return guard([&] {
+    need(v && host, "null argument");
+    hip_check(hipStreamSynchronize(v->ctx->ctx.stream), "sync");
+    v->buf.download(host, v->n);
+  });
+}
+int mgb_csr_create(mgb_ctx ctx, int rows, int cols, const int32_t* rowptr, const int32_t* colidx, const double* vals,
+                   mgb_csr* out) {
+  return guard([&] {
+    need(ctx && out, "null argument");
+    hip_check(hipSetDevice(ctx->ctx.device), "hipSetDevice");
+    Csr A = make_csr(rows, cols, rowptr, colidx, vals, "mgb_csr_create");
+    auto* m = new mgb_csr_s{ctx, {}};
+    try {
+      m->A.upload(A);
+    } catch (...) {
+      delete m;
+      throw;
+    }
+    *out = m;
+  });
+}
+int mgb_csr_free(mgb_csr A) {
+  return guard([&] { delete A; });
+}
+int mgb_diag(mgb_ctx ctx, mgb_vec z, int m, int n, mgb_csr* out) {
+  return guard([&] {
+    need(ctx && z && out && m >= 0 && n >= 0, "diag: bad arguments");
+    const int d = std::min(std::min(m, n), z->n);
+    std::vector<double> h(z->n);
+    hip_check(hipStreamSynchronize(ctx->ctx.stream), "sync");
+    z->buf.download(h.data(), z->n);
+    Csr A(m, n);
+    for (int i = 0; i < m; ++i) {
+      if (i < d) {
+        A.colidx.push_back(i);
+        A.vals.push_back(h[i]);
+      }
+      A.rowptr[i + 1] = (int)A.colidx.size();
+    }
+    auto* M = new mgb_csr_s{ctx, {}};
+    try {
+      M->A.upload(A);
+    } catch (...) {
+      delete M;
+      throw;
+    }
+    *out = M;
+  });
+}
+int mgb_spmv_add(mgb_csr A, mgb_vec x, mgb_vec y0, mgb_vec y) {
+  return guard([&] {
+    need(A && x && y, "null argument");
+    need(A->A.view.cols == x->n && A->A.view.rows == y->n && (!y0 || y0->n == y->n), "spmv: shape mismatch");
+    launch_spmv(A->ctx->ctx.stream, A->A.view, x->buf.p, y0 ? y0->buf.p : nullptr, y->buf.p);
+    hip_check(hipGetLastError(), "spmv launch");
+  });
+}
+int mgb_spmv(mgb_csr A, mgb_vec x, mgb_vec y) { return mgb_spmv_add(A, x, nullptr, y); }
+int mgb_dot(mgb_vec x, mgb_vec y, double* out) {
+  return guard([&] {
+    need(x && y && out && x->n == y->n, "dot: shape mismatch");
+    hipStream_t st = x->ctx->ctx.stream;
+    DevBuf<double> scratch;
+    scratch.alloc((size_t)f0_blocks(x->n) + 1);
+    launch_dot(st, x->n, x->buf.p, y->buf.p, scratch.p, scratch.p + f0_blocks(x->n));
+    hip_check(hipStreamSynchronize(st), "sync dot");
+    hip_check(hipMemcpy(out, scratch.p + f0_blocks(x->n), sizeof(double), hipMemcpyDeviceToHost), "D2H");
+    if (x->n == 0) *out = 0.0;
+  });
+}
+int mgb_mul(mgb_vec x, mgb_vec y, mgb_vec out) {
+  return guard([&] {
+    need(x && y && out && x->n == y->n && x->n == out->n, "mul: shape mismatch");
+    launch_mul(x->ctx->ctx.stream, x->n, x->buf.p, y->buf.p, out->buf.p);
+  });
+}
+int mgb_axpy(mgb_vec x, double alpha, mgb_vec y, mgb_vec out) {
+  return guard([&] {
+    need(x && y && out && x->n == y->n && x->n == out->n, "axpy: shape mismatch");
+    launch_waxpby(x->ctx->ctx.stream, x->n, x->buf.p, alpha, y->buf.p, out->buf.p);
+  });
+}
+int mgb_all_isfinite(mgb_vec x, int* out) {
+  return guard([&] {
+    need(x && out, "null argument");
+    hipStream_t st = x->ctx->ctx.stream;
+    DevBuf<int> flag;
+    flag.alloc(1);
+    launch_all_isfinite(st, x->n, x->buf.p, flag.p);
+    hip_check(hipStreamSynchronize(st), "sync");
+    int h = 0;
+    flag.download(&h, 1);
+    *out = h != 0;
+  });
+}
+
+// ---- AMG
+int mgb_amg_create(mgb_ctx ctx, mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D, int nq,
+                   const int* idx_q, int idx_s, double p, mgb_amg* out) {
+  return guard([&] {
+    need(ctx && g && out, "null argument");
+    AmgSpec spec = make_spec(S, state_vars, K, D);
+    BarrierParams P = make_params(K, nq, idx_q, idx_s, p);
+    auto* a = new mgb_amg_s{ctx, nullptr, {}};
+    try {
+      const auto t0 = std::chrono::steady_clock::now();
+      a->amg.reset(new Amg(ctx->ctx, g->g, spec, P));
+      a->stats.t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } catch (...) {
+      delete a;
+      throw;
+    }
+    *out = a;
+  });
+}
+int mgb_amg_destroy(mgb_amg a) {
+  return guard([&] { delete a; });
+}
+int mgb_amg_dims(mgb_amg a, int* n, int* S, int* K, int* L, int* nY) {
+  return guard([&] {
+    need(a, "null amg");
+    if (n) *n = a->amg->n();
+    if (S) *S = a->amg->S();
+    if (K) *K = a->amg->K();
+    if (L) *L = a->amg->L();
+    if (nY) *nY = a->amg->params().nY();
+  });
+}
+int mgb_amg_level_size(mgb_amg a, int level, int* N, int* nnz_lower) {
+  return guard([&] {
+    need(a && level >= 0 && level < a->amg->L(), "level out of range");
+    if (N) *N = a->amg->plan(level).N;
+    if (nnz_lower) *nnz_lower = a->amg->plan(level).Apat.nnz();
+  });
+}
+int mgb_amg_hessian_pattern(mgb_amg a, int level, int32_t* rowptr, int32_t* colidx) {
+  return guard([&] {
+    need(a && level >= 0 && level < a->amg->L(), "level out of range");
+    const Csr& A = a->amg->plan(level).Apat;
+    if (rowptr) std::copy(A.rowptr.begin(), A.rowptr.end(), rowptr);
+    if (colidx) std::copy(A.colidx.begin(), A.colidx.end(), colidx);
+  });
+}
+int mgb_amg_set_c(mgb_amg a, const double* c) {
+  return guard([&] {
+    need(a && c, "null argument");
+    a->amg->set_c(c);
+  });
+}
+int mgb_amg_set_z(mgb_amg a, const double* z) {
+  return guard([&] {
+    need(a && z, "null argument");
+    a->amg->set_z(z);
+  });
+}
+int mgb_amg_get_z(mgb_amg a, double* z) {
+  return guard([&] {
+    need(a && z, "null argument");
+    a->amg->get_z(z);
+  });
+}
+int mgb_amg_apply_D(mgb_amg a, int level, const double* s, double* Dz) {
+  return guard([&] {
+    need(a && s && Dz && level >= 0 && level < a->amg->L(), "apply_D: bad arguments");
+    a->amg->apply_D(level, s, Dz);
+  });
+}
+int mgb_amg_f0(mgb_amg a, int level, const double* s, double t, double* y, double* parts2) {
+  return guard([&] {
+    need(a && s && y && level >= 0 && level < a->amg->L(), "f0: bad arguments");
+    *y = a->amg->f0(level, s, t, parts2);
+  });
+}
+int mgb_amg_f1(mgb_amg a, int level, const double* s, double t, double* g) {
+  return guard([&] {
+    need(a && s && g && level >= 0 && level < a->amg->L(), "f1: bad arguments");
+    a->amg->f1(level, s, t, g);
+  });
+}
+int mgb_amg_f2(mgb_amg a, int level, const double* s, double t, double* lower_vals) {
+  return guard([&] {
+    need(a && s && lower_vals && level >= 0 && level < a->amg->L(), "f2: bad arguments");
+    a->amg->f2(level, s, t, lower_vals);
+  });
+}
+int mgb_amg_solve_linear(mgb_amg a, int level, const double* lower_vals, const double* g, double* x) {
+  return guard([&] {
+    need(a && lower_vals && g && x && level >= 0 && level < a->amg->L(), "solve_linear: bad arguments");
+    if (!a->amg->solve_host(level, lower_vals, g, x)) throw std::runtime_error("MfChol: matrix is not positive definite");
+  });
+}
+int mgb_amg_solve(mgb_amg a, double tol, double t0, double kappa, int maxit, int max_newton, int verbose) {
+  return guard([&] {
+    need(a, "null amg");
+    SolveOptions o;
+    if (tol > 0) o.tol = tol;
+    if (t0 > 0) o.t0 = t0;
+    if (kappa > 1) o.kappa = kappa;
+    if (maxit > 0) o.maxit = maxit;
+    if (max_newton > 0) o.max_newton = max_newton;
+    o.verbose = verbose;
+    const double ts = a->stats.t_setup;
+    a->amg->solve(o, a->stats);
+    a->stats.t_setup = ts;
+  });
+}
+int mgb_amg_sol_info(mgb_amg a, int* nt, double* t_elapsed, double* time_factor, long long* counts4) {
+  return guard([&] {
+    need(a, "null amg");
+    if (nt) *nt = (int)a->stats.ts.size();
+    if (t_elapsed) *t_elapsed = a->stats.t_elapsed;
+    if (time_factor) *time_factor = a->stats.time_factor;
+    if (counts4) {
+      counts4[0] = a->stats.n_f0;
+      counts4[1] = a->stats.n_f1;
+      counts4[2] = a->stats.n_f2;
+      counts4[3] = a->stats.n_factor;
+    }
+  });
+}
+int mgb_amg_sol_get(mgb_amg a, long long* its, double* ts, double* c_dot_Dz) {
+  return guard([&] {
+    need(a, "null amg");
+    if (its) std::copy(a->stats.its.begin(), a->stats.its.end(), its);
+    if (ts) std::copy(a->stats.ts.begin(), a->stats.ts.end(), ts);
+    if (c_dot_Dz) std::copy(a->stats.c_dot_Dz.begin(), a->stats.c_dot_Dz.end(), c_dot_Dz);
+  });
+}
+int mgb_amg_time_kernels(mgb_amg a, int level, int reps, double* ms6, double* bytes6) {
+  return guard([&] {
+    need(a && ms6 && bytes6 && reps > 0 && level >= 0 && level < a->amg->L(), "time_kernels: bad arguments");
+    Amg::KernelTimes k = a->amg->time_kernels(level, reps);
+    const double ms[6] = {k.apply_ms, k.f2_ms, k.assemble_ms, k.f1_ms, k.restrict_ms, k.f0_ms};
+    const double by[6] = {k.apply_bytes, k.f2_bytes, k.assemble_bytes, k.f1_bytes, k.restrict_bytes, k.f0_bytes};
+    std::copy(ms, ms + 6, ms6);
+    std::copy(by, by + 6, bytes6);
+  });
+}
+
+// ---- host-only helpers
+int mgb_plan_create(mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D, int nq,
+                    const int* idx_q, int idx_s, int level, mgb_plan* out) {
+  return guard([&] {
+    need(g && out, "null argument");
+    AmgSpec spec = make_spec(S, state_vars, K, D);
+    BarrierParams P = make_params(K, nq, idx_q, idx_s, 1.0);
+    Csr Dstack = build_dstack(g->g, spec);
+    auto* p = new mgb_plan_s;
+    try {
+      p->plan = build_level_plan(g->g, spec, Dstack, level, P);
+      p->n = g->g.n;
+      p->nY = P.nY();
+    } catch (...) {
+      delete p;
+      throw;
+    }
+    *out = p;
+  });
+}
+int mgb_plan_destroy(mgb_plan p) {
+  return guard([&] { delete p; });
+}
+int mgb_plan_sizes(mgb_plan p, int* N, int* nnz_lower, int* nnz_T, int* nnz_B) {
+  return guard([&] {
+    need(p, "null plan");
+    if (N) *N = p->plan.N;
+    if (nnz_lower) *nnz_lower = p->plan.Apat.nnz();
+    if (nnz_T) *nnz_T = p->plan.T.nnz();
+    if (nnz_B) *nnz_B = p->plan.B.nnz();
+  });
+}
+int mgb_plan_pattern(mgb_plan p, int32_t* rowptr, int32_t* colidx) {
+  return guard([&] {
+    need(p, "null plan");
+    if (rowptr) std::copy(p->plan.Apat.rowptr.begin(), p->plan.Apat.rowptr.end(), rowptr);
+    if (colidx) std::copy(p->plan.Apat.colidx.begin(), p->plan.Apat.colidx.end(), colidx);
+  });
+}
+int mgb_plan_eval_host(mgb_plan p, const double* Y, double* lower_vals) {
+  return guard([&] {
+    need(p && Y && lower_vals, "null argument");
+    spmv_host(p->plan.T, Y, lower_vals);
+  });
+}
+
+int mgb_chol_selftest(int nx, int ny, double* max_residual, double* flops, double* seconds) {
+  return guard([&] {
+    need(nx > 0 && ny > 0, "selftest: bad size");
+    const int N = nx * ny;
+    std::vector<Triplet> t;
+    std::vector<double> coords((size_t)N * 2);
+    for (int j = 0; j < ny; ++j)
+      for (int i = 0; i < nx; ++i) {
+        const int r = j * nx + i;
+        coords[2 * r] = i;
+        coords[2 * r + 1] = j;
+        t.push_back({r, r, 6.0 + 1e-3 * ((r * 7919) % 13)});
+        if (i > 0) t.push_back({r, r - 1, -1.0});
+        if (j > 0) t.push_back({r, r - nx, -1.0});
+        if (i > 0 && j > 0) t.push_back({r, r - nx - 1, -0.5});
+      }
+    Csr Lo = from_triplets(N, N, t);
+    MfChol ch;
+    ch.analyze(Lo, coords.data(), 2);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!ch.factor(Lo.vals.data())) throw std::runtime_error("MfChol: selftest matrix not SPD");
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<double> xs(N), b(N, 0.0);
+    for (int i = 0; i < N; ++i) xs[i] = std::sin(0.37 * i) + 0.1;
+    for (int r = 0; r < N; ++r)
+      for (int k = Lo.rowptr[r]; k < Lo.rowptr[r + 1]; ++k) {
+        const int c = Lo.colidx[k];
+        b[r] += Lo.vals[k] * xs[c];
+        if (c != r) b[c] += Lo.vals[k] * xs[r];
+      }
+    ch.solve(b.data());
+    double mx = 0;
+    for (int i = 0; i < N; ++i) mx = std::max(mx, std::fabs(b[i] - xs[i]));
+    if (max_residual) *max_residual = mx;
+    if (flops) *flops = ch.factor_flops();
+    if (seconds) *seconds = sec;
+  });
+}
+
+}  // extern "C"

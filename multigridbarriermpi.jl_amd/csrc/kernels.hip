@@ -1,0 +1,273 @@
+// gfx950 (CDNA4, wave64) kernels for the multigrid-barrier Newton path.
+//
+// Roofline: every kernel here is HBM/L2-bandwidth bound (AI ~0.1-0.3 flop/B, fp64); no MFMA.
+//   spmv_kernel<G>   bytes = nnz*12 + (rows+1)*4 + 8*(touched x) + rows*8 (+ rows*8 if y0)
+//   barrier_f0       bytes = n*(2K+1)*8                 (Dz, c, w)            -> 2 scalars
+//   barrier_f1       bytes = n*(3K+1)*8                 (Dz, c, w -> v)
+//   barrier_f2       bytes = n*(K+1+nY)*8               (Dz, w -> Y)
+// Reference functions replaced: a3 apply_D (K SpMVs + hcat), a4/a5/a6 map_rows of the
+// barrier F/F1/F2 (src/MultiGridBarrierMPI.jl:161-170), a8 amgb_all_isfinite (src:121-133),
+// a9 dot/.* / column extract (test/test_column_extract.jl:50-66).
+#include "kernels.hpp"
+
+#include <cmath>
+
+namespace mgb {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 2048;  // >= 8 blocks per CU on 256 CUs; grid-stride beyond that
+
+inline int grid_for(long long work_items) {
+  long long b = (work_items + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------- SpMV
+// G lanes cooperate on one row: lane j reads nonzero j, j+G, ... (coalesced across the group and,
+// because consecutive rows are adjacent in CSR storage, across the 64/G rows of a wave); the
+// G partial sums are combined with a fixed-order shuffle tree -> bitwise reproducible.
+template <int G>
+__global__ __launch_bounds__(kBlock) void spmv_kernel(int rows, const int* __restrict__ rowptr,
+                                                       const int* __restrict__ colidx,
+                                                       const double* __restrict__ vals,
+                                                       const double* __restrict__ x, const double* y0, double* y) {
+  const int lane = threadIdx.x % G;
+  const long long stride = (long long)gridDim.x * (kBlock / G);
+  for (long long row = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G; row < rows; row += stride) {
+    const int b = rowptr[row], e = rowptr[row + 1];
+    double acc = 0.0;
+    for (int k = b + lane; k < e; k += G) acc += vals[k] * x[colidx[k]];
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, G);
+    if (lane == 0) y[row] = (y0 ? y0[row] : 0.0) + acc;
+  }
+}
+
+template <int G>
+void spmv_launch(hipStream_t st, const DevCsr& A, const double* x, const double* y0, double* y) {
+  const int grid = grid_for((long long)A.rows * G);
+  hipLaunchKernelGGL(spmv_kernel<G>, dim3(grid), dim3(kBlock), 0, st, A.rows, A.rowptr, A.colidx, A.vals, x, y0, y);
+}
+
+// ---------------------------------------------------------------- reductions
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// sum over the block in a fixed order; result valid in thread 0
+__device__ inline double block_sum(double v, double* lds) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) lds[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kBlock / 64; ++i) r += lds[i];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(kBlock) void final_sum_kernel(int nparts, int nout, const double* __restrict__ partials,
+                                                            double* out) {
+  __shared__ double lds[kBlock / 64];
+  for (int o = 0; o < nout; ++o) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += kBlock) acc += partials[(size_t)i * nout + o];
+    double r = block_sum(acc, lds);
+    if (threadIdx.x == 0) out[o] = r;
+  }
+}
+
+// ---------------------------------------------------------------- barrier
+struct Cone {
+  double q[3];
+  double s, phi, sa;  // sa = s^a
+  bool ok;
+};
+
+__device__ inline double pow_a(double s, double a) {
+  if (a == 2.0) return s * s;
+  if (a == 1.0) return s;
+  return pow(s, a);
+}
+
+__device__ inline Cone load_cone(const BarrierParams& P, const double* dz) {
+  Cone c;
+  double qq = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    c.q[i] = (i < P.nq) ? dz[P.iq[i]] : 0.0;
+    qq += c.q[i] * c.q[i];
+  }
+  c.s = dz[P.is];
+  c.ok = c.s > 0.0;
+  c.sa = c.ok ? pow_a(c.s, P.a) : -1.0;
+  c.phi = c.sa - qq;
+  c.ok = c.ok && (c.phi > 0.0);
+  return c;
+}
+
+__global__ __launch_bounds__(kBlock) void barrier_f0_kernel(int n, BarrierParams P, const double* __restrict__ Dz,
+                                                             const double* __restrict__ w,
+                                                             const double* __restrict__ c, double* partials) {
+  __shared__ double lds[kBlock / 64];
+  double accF = 0.0, accL = 0.0;
+  for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < n; q += (long long)gridDim.x * kBlock) {
+    const double* dz = Dz + q * P.K;
+    const double* cq = c + q * P.K;
+    const double wq = w[q];
+    Cone k = load_cone(P, dz);
+    const double F = k.ok ? (-log(k.phi) - P.mu * log(k.s)) : INFINITY;
+    accF += wq * F;
+    double lin = 0.0;
+    for (int j = 0; j < P.K; ++j) lin += cq[j] * dz[j];
+    accL += wq * lin;
+  }
+  double rF = block_sum(accF, lds);
+  double rL = block_sum(accL, lds);
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = rF;
+    partials[2 * blockIdx.x + 1] = rL;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void barrier_f1_kernel(int n, BarrierParams P, const double* __restrict__ Dz,
+                                                             const double* __restrict__ w,
+                                                             const double* __restrict__ c, double t, double* v) {
+  for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < n; q += (long long)gridDim.x * kBlock) {
+    const double* dz = Dz + q * P.K;
+    const double* cq = c + q * P.K;
+    double* vq = v + q * P.K;
+    const double wq = w[q];
+    Cone k = load_cone(P, dz);
+    const double ds = P.a * pow_a(k.s, P.a - 1.0);  // d(s^a)/ds
+    for (int j = 0; j < P.K; ++j) vq[j] = wq * (t * cq[j]);
+    for (int i = 0; i < P.nq; ++i) vq[P.iq[i]] = wq * (2.0 * k.q[i] / k.phi + t * cq[P.iq[i]]);
+    vq[P.is] = wq * (-ds / k.phi - P.mu / k.s + t * cq[P.is]);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void barrier_f2_kernel(int n, BarrierParams P, const double* __restrict__ Dz,
+                                                             const double* __restrict__ w, double* Y) {
+  const int nact = P.nq + 1, nY = nact * (nact + 1) / 2;
+  for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < n; q += (long long)gridDim.x * kBlock) {
+    const double* dz = Dz + q * P.K;
+    double* yq = Y + q * nY;
+    const double wq = w[q];
+    Cone k = load_cone(P, dz);
+    const double a = P.a;
+    const double ds = a * pow_a(k.s, a - 1.0);
+    const double dds = (a == 1.0) ? 0.0 : a * (a - 1.0) * pow_a(k.s, a - 2.0);
+    const double ip = 1.0 / k.phi, ip2 = ip * ip;
+    int slot = 0;
+    for (int i = 0; i < P.nq; ++i) {
+      for (int j = i; j < P.nq; ++j) yq[slot++] = wq * (4.0 * k.q[i] * k.q[j] * ip2 + (i == j ? 2.0 * ip : 0.0));
+      yq[slot++] = wq * (-2.0 * k.q[i] * ds * ip2);
+    }
+    yq[slot] = wq * (-dds * ip + ds * ds * ip2 + P.mu / (k.s * k.s));
+  }
+}
+
+// ---------------------------------------------------------------- vector ops
+__global__ __launch_bounds__(kBlock) void waxpby_kernel(int n, const double* __restrict__ x, double alpha,
+                                                         const double* __restrict__ y, double* out) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+    out[i] = x[i] + alpha * y[i];
+}
+
+__global__ __launch_bounds__(kBlock) void mul_kernel(int n, const double* __restrict__ x, const double* __restrict__ y,
+                                                      double* out) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+    out[i] = x[i] * y[i];
+}
+
+__global__ __launch_bounds__(kBlock) void col_extract_kernel(int n, int K, int k, const double* __restrict__ M,
+                                                              double* out) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+    out[i] = M[i * K + k];
+}
+
+__global__ __launch_bounds__(kBlock) void dot_kernel(int n, const double* __restrict__ x, const double* __restrict__ y,
+                                                      double* partials) {
+  __shared__ double lds[kBlock / 64];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+    acc += x[i] * y[i];
+  double r = block_sum(acc, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(kBlock) void isfinite_kernel(int n, const double* __restrict__ x, int* flag) {
+  int bad = 0;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+    bad |= !isfinite(x[i]);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
+}
+
+}  // namespace
+
+void launch_spmv(hipStream_t st, const DevCsr& A, const double* x, const double* y0, double* y) {
+  if (A.rows == 0) return;
+  switch (A.group) {
+    case 1: spmv_launch<1>(st, A, x, y0, y); break;
+    case 2: spmv_launch<2>(st, A, x, y0, y); break;
+    case 4: spmv_launch<4>(st, A, x, y0, y); break;
+    case 8: spmv_launch<8>(st, A, x, y0, y); break;
+    case 16: spmv_launch<16>(st, A, x, y0, y); break;
+    case 32: spmv_launch<32>(st, A, x, y0, y); break;
+    default: spmv_launch<64>(st, A, x, y0, y); break;
+  }
+}
+
+void launch_waxpby(hipStream_t st, int n, const double* x, double alpha, const double* y, double* out) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(waxpby_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, x, alpha, y, out);
+}
+
+int f0_blocks(int n) { return grid_for(n); }
+
+void launch_barrier_f0(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
+                       double* partials, double* out2) {
+  const int grid = grid_for(n);
+  hipLaunchKernelGGL(barrier_f0_kernel, dim3(grid), dim3(kBlock), 0, st, n, P, Dz, w, c, partials);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, grid, 2, partials, out2);
+}
+
+void launch_barrier_f1(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
+                       double t, double* v) {
+  hipLaunchKernelGGL(barrier_f1_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, P, Dz, w, c, t, v);
+}
+
+void launch_barrier_f2(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, double* Y) {
+  hipLaunchKernelGGL(barrier_f2_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, P, Dz, w, Y);
+}
+
+void launch_dot(hipStream_t st, int n, const double* x, const double* y, double* partials, double* out) {
+  const int grid = grid_for(n);
+  hipLaunchKernelGGL(dot_kernel, dim3(grid), dim3(kBlock), 0, st, n, x, y, partials);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, grid, 1, partials, out);
+}
+
+void launch_all_isfinite(hipStream_t st, int n, const double* x, int* flag) {
+  (void)hipMemsetAsync(flag, 0xFF, sizeof(int), st);  // all-ones == true; kernel ANDs it to 0
+  if (n == 0) return;
+  hipLaunchKernelGGL(isfinite_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, x, flag);
+}
+
+void launch_mul(hipStream_t st, int n, const double* x, const double* y, double* out) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, x, y, out);
+}
+
+void launch_col_extract(hipStream_t st, int n, int K, int k, const double* M, double* out) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(col_extract_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, K, k, M, out);
+}
+
+}  // namespace mgb

@@ -1,0 +1,53 @@
+// Launchers for the gfx950 kernels of the multigrid-barrier Newton path (kernels.hip).
+// Everything here is fp64 values / Int32 indices (reference: T=Float64, Ti=Int32, src:260,559).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mgb {
+
+// Device CSR (row-block of an HPCSparseMatrix: local CSR of the owned rows, reference layout
+// test/test_dump_matrices.jl:62-71).  `group` = lanes cooperating on one row (power of two <= 64).
+struct DevCsr {
+  int rows = 0, cols = 0, nnz = 0, group = 1;
+  int* rowptr = nullptr;
+  int* colidx = nullptr;
+  double* vals = nullptr;
+};
+
+// Power-cone barrier  Q = {(q,s): s >= |q|^p}:  F = -log(s^(2/p) - |q|^2) - mu log s, acting on
+// columns iq[0..nq) and is of the n x K row-major matrix Dz.
+struct BarrierParams {
+  int K = 0;
+  int nq = 0;
+  int iq[3] = {0, 0, 0};
+  int is = 0;
+  double a = 2.0;   // 2/p
+  double mu = 1.0;
+  int nact() const { return nq + 1; }
+  int nY() const { return (nq + 1) * (nq + 2) / 2; }
+};
+
+// y = (y0 ? y0 : 0) + A x      (y may alias y0)
+void launch_spmv(hipStream_t st, const DevCsr& A, const double* x, const double* y0, double* y);
+// out = x + alpha*y
+void launch_waxpby(hipStream_t st, int n, const double* x, double alpha, const double* y, double* out);
+// out2[0] = sum_q w F(Dz_q) ; out2[1] = sum_q w <c_q, Dz_q>   (+inf / NaN if any row infeasible)
+// partials: scratch of 2*f0_blocks(n) doubles.
+int f0_blocks(int n);
+void launch_barrier_f0(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
+                       double* partials, double* out2);
+// v[q,k] = w_q (dF/dDz_k + t c[q,k])
+void launch_barrier_f1(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
+                       double t, double* v);
+// Y[q,slot(a,b)] = w_q d2F/dDz_a dDz_b over the active columns (a<=b), slot = a*nact - a(a-1)/2 + (b-a)
+void launch_barrier_f2(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, double* Y);
+// out[0] = sum x_i y_i ; partials scratch of f0_blocks(n) doubles
+void launch_dot(hipStream_t st, int n, const double* x, const double* y, double* partials, double* out);
+// flag[0] = 1 if all finite else 0
+void launch_all_isfinite(hipStream_t st, int n, const double* x, int* flag);
+// out = x .* y
+void launch_mul(hipStream_t st, int n, const double* x, const double* y, double* out);
+// gather a column of a row-major n x K matrix: out[q] = M[q*K + k]
+void launch_col_extract(hipStream_t st, int n, int K, int k, const double* M, double* out);
+
+}  // namespace mgb

@@ -1,0 +1,402 @@
+#include "mfchol.hpp"
+
+#include <atomic>
+#include <cmath>
+#include <thread>
+
+namespace mgb {
+
+namespace {
+
+int hw_threads() {
+  static int n = [] {
+    const char* e = getenv("MGB_NUM_THREADS");
+    int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    if (v < 1) v = 1;
+    if (v > 64) v = 64;
+    return v;
+  }();
+  return n;
+}
+
+template <class F>
+void parallel_for(int n, int nthreads, F&& fn) {
+  if (nthreads <= 1 || n <= 1) {
+    for (int i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::atomic<int> next(0);
+  auto work = [&] {
+    for (;;) {
+      int i = next.fetch_add(1);
+      if (i >= n) break;
+      fn(i);
+    }
+  };
+  std::vector<std::thread> th;
+  int nt = std::min(nthreads, n);
+  for (int t = 1; t < nt; ++t) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+}
+
+// C(m x m, lower, ld) -= P(m x kw, ld) * P^T for columns [j0, j1) ; C and P column-major.
+inline void syrk_cols(int m, int kw, const double* P, int ld, double* C, int j0, int j1) {
+  int j = j0;
+  for (; j + 4 <= j1; j += 4) {
+    double* c0 = C + (size_t)j * ld;
+    double* c1 = c0 + ld;
+    double* c2 = c1 + ld;
+    double* c3 = c2 + ld;
+    // 4x4 triangle on the diagonal
+    for (int k = 0; k < kw; ++k) {
+      const double* p = P + (size_t)k * ld;
+      const double a0 = p[j], a1 = p[j + 1], a2 = p[j + 2], a3 = p[j + 3];
+      c0[j] -= a0 * a0;
+      c0[j + 1] -= a1 * a0;
+      c0[j + 2] -= a2 * a0;
+      c0[j + 3] -= a3 * a0;
+      c1[j + 1] -= a1 * a1;
+      c1[j + 2] -= a2 * a1;
+      c1[j + 3] -= a3 * a1;
+      c2[j + 2] -= a2 * a2;
+      c2[j + 3] -= a3 * a2;
+      c3[j + 3] -= a3 * a3;
+    }
+    // rows below, tiled so the four C columns stay in L1 while the panel streams
+    for (int i0 = j + 4; i0 < m; i0 += 256) {
+      const int i1 = std::min(m, i0 + 256);
+      for (int k = 0; k < kw; ++k) {
+        const double* p = P + (size_t)k * ld;
+        const double a0 = p[j], a1 = p[j + 1], a2 = p[j + 2], a3 = p[j + 3];
+        for (int i = i0; i < i1; ++i) {
+          const double v = p[i];
+          c0[i] -= v * a0;
+          c1[i] -= v * a1;
+          c2[i] -= v * a2;
+          c3[i] -= v * a3;
+        }
+      }
+    }
+  }
+  for (; j < j1; ++j) {
+    double* c = C + (size_t)j * ld;
+    for (int k = 0; k < kw; ++k) {
+      const double* p = P + (size_t)k * ld;
+      const double a = p[j];
+      for (int i = j; i < m; ++i) c[i] -= p[i] * a;
+    }
+  }
+}
+
+// Partial Cholesky of the first ns pivots of the nf x nf column-major lower front F.
+bool partial_chol(double* F, int nf, int ns, int nthreads) {
+  const int NB = 48;
+  for (int kb = 0; kb < ns; kb += NB) {
+    const int kw = std::min(NB, ns - kb);
+    for (int k = kb; k < kb + kw; ++k) {
+      double* ck = F + (size_t)k * nf;
+      double d = ck[k];
+      if (!(d > 0.0) || !std::isfinite(d)) return false;
+      d = std::sqrt(d);
+      ck[k] = d;
+      const double inv = 1.0 / d;
+      for (int i = k + 1; i < nf; ++i) ck[i] *= inv;
+      for (int j = k + 1; j < kb + kw; ++j) {
+        double* cj = F + (size_t)j * nf;
+        const double a = ck[j];
+        for (int i = j; i < nf; ++i) cj[i] -= ck[i] * a;
+      }
+    }
+    const int r0 = kb + kw;  // trailing block starts here
+    const int m = nf - r0;
+    if (m <= 0) continue;
+    const double* P = F + (size_t)kb * nf + r0;     // rows r0.., columns kb..kb+kw
+    double* C = F + (size_t)r0 * nf + r0;
+    if (nthreads > 1 && (double)m * m * kw > 4e6) {
+      // column strips with roughly equal triangle area
+      const int nchunk = nthreads * 4;
+      std::vector<int> cut(nchunk + 1);
+      for (int c = 0; c <= nchunk; ++c) {
+        double frac = 1.0 - std::sqrt(1.0 - (double)c / nchunk);
+        cut[c] = std::min(m, (int)(frac * m) / 4 * 4);
+      }
+      cut[nchunk] = m;
+      parallel_for(nchunk, nthreads, [&](int c) {
+        if (cut[c + 1] > cut[c]) syrk_cols(m, kw, P, nf, C, cut[c], cut[c + 1]);
+      });
+    } else {
+      syrk_cols(m, kw, P, nf, C, 0, m);
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const double* coords, int dim, int leaf,
+                  std::vector<int>& label, int& next_label, std::vector<std::vector<int>>& own) {
+  const int cnt = hi - lo;
+  auto make_leaf = [&] {
+    nodes_.emplace_back();
+    own.emplace_back(dofs.begin() + lo, dofs.begin() + hi);
+    return (int)nodes_.size() - 1;
+  };
+  if (cnt <= leaf) return make_leaf();
+  // widest axis
+  int axis = 0;
+  double best = -1;
+  for (int d = 0; d < dim; ++d) {
+    double mn = 1e300, mx = -1e300;
+    for (int i = lo; i < hi; ++i) {
+      double c = coords[(size_t)dofs[i] * dim + d];
+      mn = std::min(mn, c);
+      mx = std::max(mx, c);
+    }
+    if (mx - mn > best) {
+      best = mx - mn;
+      axis = d;
+    }
+  }
+  const int midp = lo + cnt / 2;
+  std::nth_element(dofs.begin() + lo, dofs.begin() + midp, dofs.begin() + hi, [&](int a, int b) {
+    double ca = coords[(size_t)a * dim + axis], cb = coords[(size_t)b * dim + axis];
+    return ca != cb ? ca < cb : a < b;
+  });
+  const int tagA = next_label++, tagB = next_label++;
+  for (int i = lo; i < midp; ++i) label[dofs[i]] = tagA;
+  for (int i = midp; i < hi; ++i) label[dofs[i]] = tagB;
+  // separator = A-side vertices adjacent to B
+  std::vector<int> Ap, S;
+  for (int i = lo; i < midp; ++i) {
+    const int v = dofs[i];
+    bool sep = false;
+    for (int k = A.rowptr[v]; k < A.rowptr[v + 1] && !sep; ++k) sep = (label[A.colidx[k]] == tagB);
+    (sep ? S : Ap).push_back(v);
+  }
+  if (Ap.empty() || (int)S.size() * 2 > cnt) return make_leaf();  // S empty: disconnected halves, empty separator node
+  std::vector<int> Bv(dofs.begin() + midp, dofs.begin() + hi);
+  std::copy(Ap.begin(), Ap.end(), dofs.begin() + lo);
+  std::copy(Bv.begin(), Bv.end(), dofs.begin() + lo + Ap.size());
+  std::copy(S.begin(), S.end(), dofs.begin() + lo + Ap.size() + Bv.size());
+  const int a_end = lo + (int)Ap.size(), b_end = a_end + (int)Bv.size();
+  const int cl = build(dofs, lo, a_end, A, coords, dim, leaf, label, next_label, own);
+  const int cr = build(dofs, a_end, b_end, A, coords, dim, leaf, label, next_label, own);
+  nodes_.emplace_back();
+  own.emplace_back(S);
+  const int t = (int)nodes_.size() - 1;
+  nodes_[t].children = {cl, cr};
+  nodes_[cl].parent = t;
+  nodes_[cr].parent = t;
+  return t;
+}
+
+void MfChol::analyze(const Csr& Ain, const double* coords, int dim, int leaf_size) {
+  if (Ain.rows != Ain.cols) throw std::runtime_error("MfChol: matrix not square");
+  n_ = Ain.rows;
+  // symmetric adjacency (pattern + transpose) for ordering and the symbolic phase
+  Csr A;
+  {
+    std::vector<Triplet> t;
+    t.reserve((size_t)Ain.nnz() * 2);
+    for (int r = 0; r < n_; ++r)
+      for (int k = Ain.rowptr[r]; k < Ain.rowptr[r + 1]; ++k) {
+        t.push_back({r, Ain.colidx[k], 1.0});
+        if (Ain.colidx[k] != r) t.push_back({Ain.colidx[k], r, 1.0});
+      }
+    A = from_triplets(n_, n_, std::move(t), true);
+  }
+  nodes_.clear();
+  roots_.clear();
+  std::vector<std::vector<int>> own;
+  std::vector<int> dofs(n_), label(n_, -1);
+  std::iota(dofs.begin(), dofs.end(), 0);
+  int next_label = 0;
+  if (n_ > 0) roots_.push_back(build(dofs, 0, n_, A, coords, dim, leaf_size, label, next_label, own));
+  // numbering: nodes are already in postorder
+  perm_.resize(n_);
+  iperm_.resize(n_);
+  std::vector<int> node_of(n_);
+  int cnt = 0;
+  for (size_t t = 0; t < nodes_.size(); ++t) {
+    nodes_[t].first = cnt;
+    nodes_[t].ns = (int)own[t].size();
+    std::sort(own[t].begin(), own[t].end());
+    for (int v : own[t]) {
+      perm_[cnt] = v;
+      iperm_[v] = cnt;
+      node_of[cnt] = (int)t;
+      ++cnt;
+    }
+  }
+  // symbolic: boundary index lists
+  std::vector<int> stamp(n_, -1);
+  size_t total = 0;
+  max_front_ = 0;
+  flops_ = 0;
+  for (size_t t = 0; t < nodes_.size(); ++t) {
+    Node& nd = nodes_[t];
+    const int last = nd.first + nd.ns;
+    std::vector<int>& b = nd.bdry;
+    b.clear();
+    for (int j = nd.first; j < last; ++j) {
+      const int v = perm_[j];
+      for (int k = A.rowptr[v]; k < A.rowptr[v + 1]; ++k) {
+        const int i = iperm_[A.colidx[k]];
+        if (i >= last && stamp[i] != (int)t) {
+          stamp[i] = (int)t;
+          b.push_back(i);
+        }
+      }
+    }
+    for (int c : nd.children)
+      for (int i : nodes_[c].bdry)
+        if (i >= last && stamp[i] != (int)t) {
+          stamp[i] = (int)t;
+          b.push_back(i);
+        }
+    std::sort(b.begin(), b.end());
+    nd.off = total;
+    const int nf = nd.nf();
+    total += (size_t)nf * nf;
+    max_front_ = std::max(max_front_, nf);
+    for (int k = 0; k < nd.ns; ++k) flops_ += (double)(nf - k) * (nf - k);
+  }
+  auto pos_in = [&](const Node& p, int i) -> int {
+    if (i < p.first + p.ns) {
+      if (i < p.first) throw std::runtime_error("MfChol: index below front");
+      return i - p.first;
+    }
+    auto it = std::lower_bound(p.bdry.begin(), p.bdry.end(), i);
+    if (it == p.bdry.end() || *it != i) throw std::runtime_error("MfChol: index missing from parent front");
+    return p.ns + (int)(it - p.bdry.begin());
+  };
+  for (size_t t = 0; t < nodes_.size(); ++t) {
+    Node& nd = nodes_[t];
+    nd.ea.clear();
+    if (nd.parent >= 0)
+      for (int i : nd.bdry) nd.ea.push_back(pos_in(nodes_[nd.parent], i));
+    else if (!nd.bdry.empty())
+      throw std::runtime_error("MfChol: root with boundary");
+  }
+  // assembly map
+  a_idx_.assign(nodes_.size(), {});
+  a_pos_.assign(nodes_.size(), {});
+  // every unordered pair must appear exactly once in the input (e.g. its lower triangle)
+  for (int r = 0; r < n_; ++r)
+    for (int k = Ain.rowptr[r]; k < Ain.rowptr[r + 1]; ++k) {
+      int i = iperm_[r], j = iperm_[Ain.colidx[k]];
+      if (i < j) std::swap(i, j);
+      const int t = node_of[j];
+      const Node& nd = nodes_[t];
+      a_idx_[t].push_back(k);
+      a_pos_[t].push_back(pos_in(nd, i) + nd.nf() * (j - nd.first));
+    }
+  fronts_.assign(total, 0.0);
+}
+
+void MfChol::factor_node(int t, const double* vals, bool& ok) {
+  Node& nd = nodes_[t];
+  const int nf = nd.nf();
+  double* F = fronts_.data() + nd.off;
+  std::fill(F, F + (size_t)nf * nf, 0.0);
+  const std::vector<int>& ai = a_idx_[t];
+  const std::vector<int>& ap = a_pos_[t];
+  for (size_t q = 0; q < ai.size(); ++q) F[ap[q]] += vals[ai[q]];
+  for (int c : nd.children) {
+    const Node& ch = nodes_[c];
+    const int cf = ch.nf(), cs = ch.ns, nb = (int)ch.bdry.size();
+    const double* G = fronts_.data() + ch.off;
+    for (int b = 0; b < nb; ++b) {
+      const double* gc = G + (size_t)(cs + b) * cf + cs;
+      double* fc = F + (size_t)ch.ea[b] * nf;
+      for (int a = b; a < nb; ++a) fc[ch.ea[a]] += gc[a];
+    }
+  }
+  if (!partial_chol(F, nf, nd.ns, (double)nd.ns * nf * nf > 3e7 ? hw_threads() : 1)) ok = false;
+}
+
+bool MfChol::factor(const double* vals) {
+  if (n_ == 0) return true;
+  bool ok = true;
+  const int nt = hw_threads();
+  const int nn = (int)nodes_.size();
+  // subtree sizes (postorder: subtree of t is the contiguous range [t-size+1, t])
+  std::vector<double> work(nn, 0.0);
+  std::vector<int> sz(nn, 1);
+  for (int t = 0; t < nn; ++t) {
+    const Node& nd = nodes_[t];
+    double w = 0;
+    for (int k = 0; k < nd.ns; ++k) w += (double)(nd.nf() - k) * (nd.nf() - k);
+    work[t] += w;
+    if (nd.parent >= 0) {
+      work[nd.parent] += work[t];
+      sz[nd.parent] += sz[t];
+    }
+  }
+  std::vector<int> tasks;     // roots of independent subtrees
+  std::vector<char> in_task(nn, 0);
+  if (nt > 1) {
+    const double thresh = work[nn - 1] / (4.0 * nt);
+    for (int t = nn - 1; t >= 0; --t) {
+      const int p = nodes_[t].parent;
+      if (p >= 0 && in_task[p]) {
+        in_task[t] = 1;
+        continue;
+      }
+      if (work[t] <= thresh || nodes_[t].children.empty()) {
+        in_task[t] = 1;
+        tasks.push_back(t);
+      }
+    }
+    std::sort(tasks.begin(), tasks.end(), [&](int a, int b) { return work[a] > work[b]; });
+    std::atomic<bool> aok(true);
+    parallel_for((int)tasks.size(), nt, [&](int q) {
+      const int root = tasks[q];
+      bool lok = true;
+      for (int t = root - sz[root] + 1; t <= root; ++t) factor_node(t, vals, lok);
+      if (!lok) aok = false;
+    });
+    ok = aok;
+  }
+  for (int t = 0; t < nn && ok; ++t)
+    if (!in_task[t]) factor_node(t, vals, ok);
+  return ok;
+}
+
+void MfChol::solve(double* b) const {
+  if (n_ == 0) return;
+  std::vector<double> y(n_);
+  for (int i = 0; i < n_; ++i) y[i] = b[perm_[i]];
+  std::vector<double> tmp;
+  const int nn = (int)nodes_.size();
+  for (int t = 0; t < nn; ++t) {  // forward: L y = b
+    const Node& nd = nodes_[t];
+    const int nf = nd.nf(), ns = nd.ns;
+    const double* F = fronts_.data() + nd.off;
+    double* yo = y.data() + nd.first;
+    for (int k = 0; k < ns; ++k) {
+      const double* ck = F + (size_t)k * nf;
+      const double v = yo[k] / ck[k];
+      yo[k] = v;
+      for (int i = k + 1; i < ns; ++i) yo[i] -= ck[i] * v;
+      for (int i = ns; i < nf; ++i) y[nd.bdry[i - ns]] -= ck[i] * v;
+    }
+  }
+  for (int t = nn - 1; t >= 0; --t) {  // backward: L' x = y
+    const Node& nd = nodes_[t];
+    const int nf = nd.nf(), ns = nd.ns;
+    const double* F = fronts_.data() + nd.off;
+    double* yo = y.data() + nd.first;
+    for (int k = ns - 1; k >= 0; --k) {
+      const double* ck = F + (size_t)k * nf;
+      double v = yo[k];
+      for (int i = k + 1; i < ns; ++i) v -= ck[i] * yo[i];
+      for (int i = ns; i < nf; ++i) v -= ck[i] * y[nd.bdry[i - ns]];
+      yo[k] = v / ck[k];
+    }
+  }
+  for (int i = 0; i < n_; ++i) b[perm_[i]] = y[i];
+}
+
+}  // namespace mgb

@@ -1,0 +1,57 @@
+// Fixed-pattern multifrontal Cholesky for the Newton systems  n = (R' H R) \ g.
+//
+// Reference behaviour replaced: `MultiGridBarrier.solve(A::HPCSparseMatrix, b::HPCVector) = A \ b`
+// -> MUMPS analysis+factor+solve on every Newton step at every level
+// (test/test_instrumented_solve.jl:25-28,99; tools/profile_ops.jl:117-126).  BASELINE.json keeps
+// the direct solve on the host.  Because the sparsity pattern of R_l' H R_l is fixed per level, the
+// symbolic phase (geometric nested dissection from the dof coordinates, elimination tree, front
+// index lists, assembly and extend-add maps) runs once per level; each Newton step only scatters
+// the new values, runs dense partial factorizations up the tree (OpenMP tasks over subtrees) and
+// does the two triangular sweeps.
+#pragma once
+#include <vector>
+
+#include "sparse.hpp"
+
+namespace mgb {
+
+class MfChol {
+ public:
+  // pattern: CSR pattern holding every unordered pair (i,j) exactly once, e.g. the lower triangle
+  // (values ignored); coords: N x dim (row-major) dof positions
+  // used only to choose the ordering (any values give a correct factorization).
+  void analyze(const Csr& pattern, const double* coords, int dim, int leaf_size = 64);
+  // vals aligned with pattern.colidx of analyze(); returns false on a non-positive pivot.
+  bool factor(const double* vals);
+  // in-place solve; b has N entries in the ORIGINAL ordering.
+  void solve(double* b) const;
+  int size() const { return n_; }
+  size_t front_doubles() const { return fronts_.size(); }
+  double factor_flops() const { return flops_; }
+  int num_nodes() const { return (int)nodes_.size(); }
+  int max_front() const { return max_front_; }
+
+ private:
+  struct Node {
+    int parent = -1;
+    int first = 0, ns = 0;      // own dofs: new indices [first, first+ns)
+    std::vector<int> bdry;      // boundary dofs (new indices, ascending)
+    std::vector<int> children;
+    std::vector<int> ea;        // position of bdry[i] inside the parent's front index list
+    size_t off = 0;             // offset of the nf x nf column-major front in fronts_
+    int nf() const { return ns + (int)bdry.size(); }
+  };
+  int build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const double* coords, int dim, int leaf,
+            std::vector<int>& label, int& next_label, std::vector<std::vector<int>>& own);
+  void factor_node(int t, const double* vals, bool& ok);
+  int n_ = 0, max_front_ = 0;
+  double flops_ = 0;
+  std::vector<int> perm_, iperm_;       // perm_[new] = old ; iperm_[old] = new
+  std::vector<Node> nodes_;             // postorder: children before parents
+  std::vector<int> roots_;
+  std::vector<std::vector<int>> a_idx_; // per node: indices k into vals ...
+  std::vector<std::vector<int>> a_pos_; // ... and their destination inside the front
+  std::vector<double> fronts_;
+};
+
+}  // namespace mgb

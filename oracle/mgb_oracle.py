@@ -1,0 +1,600 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) for the multigrid-barrier Newton path.
+
+This file is a numpy/scipy restatement of the algorithm behind
+``fem{1,2}d_mpi_solve`` / ``amgb`` of sloisel/MultiGridBarrierMPI.jl.  It is the
+*checker*: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` may import it.  The product path (``multigridbarriermpi.jl_amd``)
+never does.
+
+PARITY STATUS: "parity unpinned" at solve level.
+  The reference (/root/reference) is pure Julia glue; the arithmetic lives in the
+  un-vendored dependencies MultiGridBarrier.jl (compat 0.11, Project.toml:33) and
+  HPCSparseArrays.jl (compat 0.1, Project.toml:29).  Julia is not installed and the
+  reference holds no stored solve outputs.  What *is* pinned here
+  (tests/test_oracle_kats.py) are the reference's own known-answer tests:
+    * map_rows exact values            test/test_helpers.jl:129-167, test/test_map_rows.jl:27-101
+    * amgb_all_isfinite / amgb_diag / amgb_zeros / amgb_blockdiag
+                                        test/test_helpers.jl:53-121, test/test_diag.jl:28-46
+    * the Hessian recipe identity       test/test_matrix_addition.jl:39-95,
+                                        test/test_d0_construction.jl:92-185,
+                                        test/test_map_rows_compare.jl:102-179
+    * structure: fem1d L=3 -> 16 rows, R 16x7 (test/test_nonsquare.jl:28);
+      fem1d L=2 -> 8 rows (test/test_partition_debug.jl:34);
+      fem2d n = 14*4^(L-1) (docs/src/guide.md:246-253).
+  Everything else (node ordering, quadrature, barrier constants, Newton/line-search/
+  t-update rules) restates the published method (S. Loisel, multigrid barrier /
+  p-Laplace papers) and is validated by PDE-level known answers, not reference numbers.
+
+Conventions (shared with the HIP product):
+  * broken (element-wise discontinuous) nodal storage: n rows = n_elements * nodes_per_element
+  * z is an (n, S) matrix of state variables (u, s); its vectorisation is column-major
+    ``[u; s]`` exactly as Julia's ``vec``/``hcat`` layout implies (test_d0_construction.jl:92-100).
+  * ``subspaces[key][l]`` has n (finest) rows for every level l
+    (test/test_hessian.jl:85-93 multiplies ``subspaces[:dirichlet][1]`` with the fine ``dx``).
+"""
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+# ----------------------------------------------------------------------------
+# Hook semantics (reference src/MultiGridBarrierMPI.jl:62-192)
+# ----------------------------------------------------------------------------
+
+
+def map_rows(f: Callable, *arrays):
+    """Row-wise map; follows src:161-163 + tools/profile_map_rows_steps.jl:57-146.
+
+    Each argument contributes its i-th row (vector -> length-1 row, matrix -> row).
+    Scalar results stack into a vector, row-vector results into a matrix.
+    """
+    A = [np.asarray(a, dtype=np.float64) for a in arrays]
+    n = A[0].shape[0]
+    rows = []
+    for i in range(n):
+        args = [a[i:i + 1] if a.ndim == 1 else a[i, :] for a in A]
+        rows.append(np.asarray(f(*args), dtype=np.float64))
+    if rows and rows[0].ndim == 0:
+        return np.array([float(r) for r in rows])
+    return np.vstack([r.reshape(1, -1) for r in rows]) if rows else np.zeros((0,))
+
+
+def amgb_all_isfinite(z) -> bool:
+    """src:121-133 (local all(isfinite) AND-reduced over ranks)."""
+    return bool(np.all(np.isfinite(np.asarray(z))))
+
+
+def amgb_diag(z, m=None, n=None):
+    """src:137-147: spdiagm(m, n, 0 => z)."""
+    z = np.asarray(z, dtype=np.float64)
+    m = len(z) if m is None else m
+    n = len(z) if n is None else n
+    return sp.diags([z], [0], shape=(m, n), format="csr")
+
+
+def amgb_zeros(m, n=None):
+    """src:66-75,116: sparse/dense zeros."""
+    return np.zeros(m) if n is None else sp.csr_matrix((m, n))
+
+
+def amgb_blockdiag(*mats):
+    """src:150."""
+    return sp.block_diag(mats, format="csr")
+
+
+# ----------------------------------------------------------------------------
+# Geometry  (MultiGridBarrier `Geometry` fields: src:318-330, docs/src/api.md:79-87)
+# ----------------------------------------------------------------------------
+
+
+@dataclass
+class Geometry:
+    discretization: dict
+    x: np.ndarray            # (n, d) broken node coordinates
+    w: np.ndarray            # (n,)   quadrature weights
+    subspaces: Dict[str, List[sp.csr_matrix]]   # key -> [n x m_l] for l = 1..L
+    operators: Dict[str, sp.csr_matrix]         # 'id','dx','dy'  (n x n)
+    refine: List[sp.csr_matrix]                 # refine[l]: n_l -> n_{l+1}; refine[L-1] = I
+    coarsen: List[sp.csr_matrix]                # coarsen[l] @ refine[l] = I
+
+
+def fem1d(L: int = 4) -> Geometry:
+    """1-D broken P1 elements on [-1,1]; 2^l elements at level l (src:547: "2^L elements").
+
+    fem1d L=3 -> 16 rows and a 16x7 Dirichlet subspace (test/test_nonsquare.jl:28).
+    """
+    def level_nodes(l):
+        ne = 2 ** l
+        edges = np.linspace(-1.0, 1.0, ne + 1)
+        return np.stack([edges[:-1], edges[1:]], axis=1).reshape(-1)  # (2*ne,)
+
+    xs = [level_nodes(l) for l in range(1, L + 1)]
+    n = xs[-1].size
+    ne = 2 ** L
+    h = 2.0 / ne
+    w = np.full(n, h / 2)
+    blk = np.array([[-1.0, 1.0], [-1.0, 1.0]]) / h
+    dx = sp.block_diag([blk] * ne, format="csr")
+    ident = sp.identity(n, format="csr")
+    # refine[l]: level l+1 (1-based l) -> l+2 ; each element -> 2 children
+    child = np.array([[1.0, 0.0], [0.5, 0.5], [0.5, 0.5], [0.0, 1.0]])
+    refine, coarsen = [], []
+    for l in range(1, L):
+        nel = 2 ** l
+        refine.append(sp.block_diag([child] * nel, format="csr"))
+        inj = np.zeros((2, 4))
+        inj[0, 0] = 1.0
+        inj[1, 3] = 1.0
+        coarsen.append(sp.block_diag([inj] * nel, format="csr"))
+    refine.append(sp.identity(n, format="csr"))
+    coarsen.append(sp.identity(n, format="csr"))
+    full, dirichlet = [], []
+    for l in range(1, L + 1):
+        nel = 2 ** l
+        # continuous dofs: nel+1 vertices
+        rows = np.arange(2 * nel)
+        cols = (rows + 1) // 2
+        S = sp.csr_matrix((np.ones(2 * nel), (rows, cols)), shape=(2 * nel, nel + 1))
+        P = S
+        for k in range(l - 1, L - 1):
+            P = refine[k] @ P
+        P = sp.csr_matrix(P)
+        full.append(P)
+        dirichlet.append(sp.csr_matrix(P[:, 1:-1]))
+    return Geometry(dict(kind="fem1d", L=L, dim=1, block=2), xs[-1].reshape(-1, 1), w,
+                    dict(full=full, dirichlet=dirichlet), dict(id=ident, dx=dx), refine, coarsen)
+
+
+# reference-triangle nodes (barycentric-free: xi, eta) in the order v1,v2,v3,m12,m23,m31,c
+_TRI_NODES = np.array([[0, 0], [1, 0], [0, 1], [.5, 0], [.5, .5], [0, .5], [1 / 3, 1 / 3]])
+_TRI_W = np.array([1 / 20] * 3 + [2 / 15] * 3 + [9 / 20])  # x area; exact for cubics
+
+
+def _tri_basis(pts):
+    """Values and (xi,eta)-derivatives of the 7 monomials spanning P2 + cubic bubble."""
+    xi, et = pts[:, 0], pts[:, 1]
+    lam = 1 - xi - et
+    V = np.stack([np.ones_like(xi), xi, et, xi * xi, xi * et, et * et, xi * et * lam], axis=1)
+    Vx = np.stack([0 * xi, 1 + 0 * xi, 0 * xi, 2 * xi, et, 0 * xi, et * lam - xi * et], axis=1)
+    Vy = np.stack([0 * xi, 0 * xi, 1 + 0 * xi, 0 * xi, xi, 2 * et, xi * lam - xi * et], axis=1)
+    return V, Vx, Vy
+
+
+def _tri_ref_mats():
+    V, Vx, Vy = _tri_basis(_TRI_NODES)
+    C = np.linalg.inv(V)
+    return C, Vx @ C, Vy @ C   # nodal coefficient map; d/dxi, d/deta at the nodes
+
+
+def fem2d(L: int = 2, K: Optional[np.ndarray] = None) -> Geometry:
+    """2-D broken P2+bubble triangles (7 nodes/element), red refinement.
+
+    n = 14 * 4^(L-1) (docs/src/guide.md:246-253).  ``K`` = (3m x 2) vertex list of the
+    coarse triangles (docs/src/guide.md:317); default = [-1,1]^2 split into 2 triangles.
+    """
+    if K is None:
+        K = np.array([[-1, -1], [1, -1], [-1, 1], [1, -1], [1, 1], [-1, 1]], dtype=np.float64)
+    K = np.asarray(K, dtype=np.float64)
+    tris = [K.reshape(-1, 3, 2)]
+    for _ in range(1, L):
+        T = tris[-1]
+        v1, v2, v3 = T[:, 0], T[:, 1], T[:, 2]
+        m12, m23, m31 = (v1 + v2) / 2, (v2 + v3) / 2, (v3 + v1) / 2
+        ch = np.stack([np.stack([v1, m12, m31], 1), np.stack([m12, v2, m23], 1),
+                       np.stack([m31, m23, v3], 1), np.stack([m23, m31, m12], 1)], axis=1)
+        tris.append(ch.reshape(-1, 3, 2))
+    C, Dxi, Det = _tri_ref_mats()
+
+    def nodes_of(T):
+        v1, v2, v3 = T[:, 0], T[:, 1], T[:, 2]
+        P = np.stack([v1, v2, v3, (v1 + v2) / 2, (v2 + v3) / 2, (v3 + v1) / 2, (v1 + v2 + v3) / 3], axis=1)
+        return P.reshape(-1, 2)
+
+    T = tris[-1]
+    ne = T.shape[0]
+    x = nodes_of(T)
+    n = x.shape[0]
+    e1, e2 = T[:, 1] - T[:, 0], T[:, 2] - T[:, 0]
+    det = e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]
+    area = np.abs(det) / 2
+    w = (area[:, None] * _TRI_W[None, :]).reshape(-1)
+    # x = v1 + e1*xi + e2*eta  ->  [dxi/dx dxi/dy; deta/dx deta/dy] = inv([e1 e2])
+    xix, xiy = e2[:, 1] / det, -e2[:, 0] / det
+    etx, ety = -e1[:, 1] / det, e1[:, 0] / det
+    bx = xix[:, None, None] * Dxi[None] + etx[:, None, None] * Det[None]
+    by = xiy[:, None, None] * Dxi[None] + ety[:, None, None] * Det[None]
+    dx = sp.block_diag(list(bx), format="csr") if ne < 4096 else _bdiag(bx)
+    dy = sp.block_diag(list(by), format="csr") if ne < 4096 else _bdiag(by)
+    ident = sp.identity(n, format="csr")
+    # refine / coarsen between consecutive levels
+    child_ref = [np.array(c, dtype=np.float64) for c in (
+        [[0, 0], [.5, 0], [0, .5]], [[.5, 0], [1, 0], [.5, .5]],
+        [[0, .5], [.5, .5], [0, 1]], [[.5, .5], [0, .5], [.5, 0]])]
+    blocks = []
+    for cr in child_ref:
+        pts = nodes_of(cr[None])              # child nodes in parent reference coords
+        Vc, _, _ = _tri_basis(pts)
+        blocks.append(Vc @ C)                 # (7 x 7) parent nodal values -> child nodal values
+    Pblk = np.vstack(blocks)                  # 28 x 7
+    Pblk[np.abs(Pblk) < 1e-14] = 0.0
+    inj = np.zeros((7, 28))
+    # parent v1,v2,v3 = child0.v1, child1.v2, child2.v3 ; m12 = child0.v2 ; m23 = child1.v3 ;
+    # m31 = child0.v3 ; centroid = centroid of the middle child (child 3)
+    for prow, frow in enumerate([0, 7 + 1, 14 + 2, 1, 7 + 2, 2, 21 + 6]):
+        inj[prow, frow] = 1.0
+    refine, coarsen = [], []
+    for l in range(1, L):
+        nel = tris[l - 1].shape[0]
+        refine.append(_bdiag(np.broadcast_to(Pblk, (nel, 28, 7))))
+        coarsen.append(_bdiag(np.broadcast_to(inj, (nel, 7, 28))))
+    refine.append(sp.identity(n, format="csr"))
+    coarsen.append(sp.identity(n, format="csr"))
+    full, dirichlet = [], []
+    for l in range(1, L + 1):
+        xl = nodes_of(tris[l - 1])
+        key = np.round(xl * (3 * 2 ** (L + 8))).astype(np.int64)
+        uniq, inv, counts = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+        inv = inv.reshape(-1)
+        nl = xl.shape[0]
+        S = sp.csr_matrix((np.ones(nl), (np.arange(nl), inv)), shape=(nl, uniq.shape[0]))
+        # boundary: an edge midpoint owned by exactly one element, its end vertices
+        loc = np.arange(nl) % 7
+        is_mid = (loc >= 3) & (loc <= 5)
+        bmid = is_mid & (counts[inv] == 1)
+        bnd = np.zeros(uniq.shape[0], dtype=bool)
+        bnd[inv[bmid]] = True
+        el = np.arange(nl) // 7
+        ends = {3: (0, 1), 4: (1, 2), 5: (2, 0)}
+        for r in np.nonzero(bmid)[0]:
+            for vv in ends[int(loc[r])]:
+                bnd[inv[el[r] * 7 + vv]] = True
+        P = S
+        for k in range(l - 1, L - 1):
+            P = refine[k] @ P
+        P = sp.csr_matrix(P)
+        P.eliminate_zeros()
+        full.append(P)
+        dirichlet.append(sp.csr_matrix(P[:, np.nonzero(~bnd)[0]]))
+    return Geometry(dict(kind="fem2d", L=L, dim=2, block=7, K=K), x, w,
+                    dict(full=full, dirichlet=dirichlet), dict(id=ident, dx=dx, dy=dy), refine, coarsen)
+
+
+def _bdiag(blocks):
+    """Block-diagonal CSR from an (ne, r, c) array of dense blocks."""
+    blocks = np.asarray(blocks)
+    ne, r, c = blocks.shape
+    rows = (np.arange(ne)[:, None, None] * r + np.arange(r)[None, :, None]) + np.zeros((1, 1, c), dtype=np.int64)
+    cols = (np.arange(ne)[:, None, None] * c + np.arange(c)[None, None, :]) + np.zeros((1, r, 1), dtype=np.int64)
+    M = sp.csr_matrix((blocks.reshape(-1), (rows.reshape(-1), cols.reshape(-1))), shape=(ne * r, ne * c))
+    M.eliminate_zeros()
+    return M
+
+
+# ----------------------------------------------------------------------------
+# AMG hierarchy (upstream `amg`; layout pinned by test/test_d0_construction.jl:82-100)
+# ----------------------------------------------------------------------------
+
+
+@dataclass
+class AMG:
+    geometry: Geometry
+    x: np.ndarray
+    w: np.ndarray
+    R: List[sp.csr_matrix]        # R[l] = blockdiag(subspaces[sv_k][l] for k)   (S*n x N_l)
+    D: List[sp.csr_matrix]        # D[k] = hcat(Z.., operators[op_k], ..Z)      (n x S*n)
+    state_variables: Sequence[Sequence[str]]
+    Dspec: Sequence[Sequence[str]]
+
+
+DEFAULT_STATE = (("u", "dirichlet"), ("s", "full"))
+DEFAULT_D = {1: (("u", "id"), ("u", "dx"), ("s", "id")),
+             2: (("u", "id"), ("u", "dx"), ("u", "dy"), ("s", "id"))}
+DEFAULT_F = {1: lambda x: np.array([0.5, 0.0, 1.0]), 2: lambda x: np.array([0.5, 0.0, 0.0, 1.0])}
+DEFAULT_G = {1: lambda x: np.array([x[0], 2.0]), 2: lambda x: np.array([x[0] ** 2 + x[1] ** 2, 100.0])}
+
+
+def amg(geometry: Geometry, state_variables=DEFAULT_STATE, D=None) -> AMG:
+    dim = geometry.discretization["dim"]
+    D = DEFAULT_D[dim] if D is None else D
+    n = geometry.x.shape[0]
+    L = len(geometry.refine)
+    names = [sv[0] for sv in state_variables]
+    R = [sp.block_diag([geometry.subspaces[sv[1]][l] for sv in state_variables], format="csr") for l in range(L)]
+    Z = sp.csr_matrix((n, n))
+    Dm = []
+    for var, op in D:
+        foo = [Z] * len(names)
+        foo[names.index(var)] = geometry.operators[op]
+        Dm.append(sp.hstack(foo, format="csr"))
+    return AMG(geometry, geometry.x, geometry.w, R, Dm, state_variables, D)
+
+
+# ----------------------------------------------------------------------------
+# Convex set + barrier (upstream `convex_Euclidian_power`, `barrier`)
+# ----------------------------------------------------------------------------
+
+
+def barrier_mu(p: float) -> float:
+    """log-s multiplicity of the power-cone barrier."""
+    return 0.0 if p == 2 else (1.0 if p < 2 else 2.0)
+
+
+@dataclass
+class PowerConeBarrier:
+    """Q = {(q, s): s >= |q|_2^p}; F = -log(s^(2/p) - |q|^2) - mu(p) log s, acting on
+    Dz[:, idx] = (q_1..q_d, s).  Vectorised over rows; closed-form F1/F2 (the Julia
+    default is ForwardDiff of F: identical up to rounding)."""
+    idx: Sequence[int]
+    p: float
+
+    def F(self, x, Y):
+        q, s = Y[:, self.idx[:-1]], Y[:, self.idx[-1]]
+        a = 2.0 / self.p
+        with np.errstate(all="ignore"):
+            phi = np.where(s > 0, np.power(np.abs(s), a), -1.0) - np.sum(q * q, axis=1)
+            val = -np.log(phi) - barrier_mu(self.p) * np.log(s)
+            val = np.where((phi > 0) & (s > 0), val, np.inf)
+        return val
+
+    def F1(self, x, Y):
+        n, K = Y.shape
+        q, s = Y[:, self.idx[:-1]], Y[:, self.idx[-1]]
+        a = 2.0 / self.p
+        mu = barrier_mu(self.p)
+        phi = np.power(s, a) - np.sum(q * q, axis=1)
+        ds = a * np.power(s, a - 1)
+        G = np.zeros((n, K))
+        G[:, self.idx[:-1]] = 2 * q / phi[:, None]
+        G[:, self.idx[-1]] = -ds / phi - mu / s
+        return G
+
+    def F2(self, x, Y):
+        n, K = Y.shape
+        qi, si = list(self.idx[:-1]), self.idx[-1]
+        q, s = Y[:, qi], Y[:, si]
+        a = 2.0 / self.p
+        mu = barrier_mu(self.p)
+        phi = np.power(s, a) - np.sum(q * q, axis=1)
+        ds = a * np.power(s, a - 1)
+        dds = a * (a - 1) * np.power(s, a - 2)
+        H = np.zeros((n, K, K))
+        for i, ci in enumerate(qi):
+            for j, cj in enumerate(qi):
+                H[:, ci, cj] = 4 * q[:, i] * q[:, j] / phi ** 2 + (2 / phi if i == j else 0.0)
+            H[:, ci, si] = H[:, si, ci] = -2 * q[:, i] * ds / phi ** 2
+        H[:, si, si] = -dds / phi + ds * ds / phi ** 2 + mu / (s * s)
+        return H
+
+
+def convex_Euclidian_power(idx, p) -> PowerConeBarrier:
+    return PowerConeBarrier(tuple(idx), float(p))
+
+
+class Barrier:
+    """upstream `barrier(F)` -> (f0, f1, f2); algebra pinned by
+    test/test_apply_d.jl:44 (apply_D), test/test_column_extract.jl:50-80 (f1 pieces) and
+    test/test_map_rows_compare.jl:102-123,165-170 (f2 + restriction)."""
+
+    def __init__(self, Q: PowerConeBarrier):
+        self.Q = Q
+
+    @staticmethod
+    def apply_D(D, z):
+        return np.stack([Dk @ z for Dk in D], axis=1)
+
+    def f0(self, s, x, w, c, R, D, z0):
+        Dz = self.apply_D(D, z0 + R @ s)
+        y = self.Q.F(x, Dz)
+        if not np.all(np.isfinite(y)):
+            return np.inf
+        return float(np.dot(w, y) + sum(np.dot(w * c[:, k], Dz[:, k]) for k in range(len(D))))
+
+    def f1(self, s, x, w, c, R, D, z0):
+        Dz = self.apply_D(D, z0 + R @ s)
+        y = self.Q.F1(x, Dz) + c
+        ret = np.zeros(D[0].shape[1])
+        for k in range(len(D)):
+            ret += D[k].T @ (w * y[:, k])
+        return R.T @ ret
+
+    def f2(self, s, x, w, c, R, D, z0):
+        Dz = self.apply_D(D, z0 + R @ s)
+        y = self.Q.F2(x, Dz)
+        return hessian_recipe(D, w, y, R)
+
+
+def hessian_recipe(D, w, y, R=None):
+    """H = sum_j D_j' diag(w.y_jj) D_j + sum_{k<j} (D_j' diag(w.y_jk) D_k + D_k' diag(w.y_jk) D_j); R'HR.
+    Literal restatement of test/test_map_rows_compare.jl:111-122,170."""
+    nD = len(D)
+    m0 = D[0].shape[1]
+    ret = sp.csr_matrix((m0, m0))
+    for j in range(nD):
+        foo = amgb_diag(w * y[:, j, j])
+        ret = ret + D[j].T @ foo @ D[j]
+        for k in range(j):
+            if not np.any(y[:, j, k]):
+                continue
+            foo = amgb_diag(w * y[:, j, k])
+            ret = ret + D[j].T @ foo @ D[k] + D[k].T @ foo @ D[j]
+    return sp.csr_matrix(R.T @ ret @ R) if R is not None else sp.csr_matrix(ret)
+
+
+# ----------------------------------------------------------------------------
+# Newton / line search / level loop / t-continuation (upstream newton, amgb_step, amgb_core)
+# ----------------------------------------------------------------------------
+
+BETA = 0.5          # backtracking factor
+ARMIJO = 0.1        # sufficient-decrease constant
+MIN_STEP = 1e-8     # give up the line search below this step length
+
+
+def solve(H, g):
+    """upstream `MultiGridBarrier.solve(A,b) = A \\ b` (test/test_instrumented_solve.jl:25-28,99)."""
+    H = sp.csc_matrix(H)
+    if H.shape[0] == 0:
+        return np.zeros(0)
+    return spla.splu(H).solve(g)
+
+
+def linesearch_backtracking(x, y, g, n, inc, F0, F1):
+    """Backtracking on s in {1, beta, beta^2, ...}: the trial must be finite
+    (`amgb_all_isfinite`, src:121) and satisfy y(x - s n) <= y - ARMIJO*s*inc."""
+    s = 1.0
+    while s >= MIN_STEP:
+        xn = x - s * n
+        yn = F0(xn)
+        if math.isfinite(yn) and yn <= y - ARMIJO * s * inc:
+            gn = F1(xn)
+            if amgb_all_isfinite(gn):
+                return xn, yn, gn, s
+        s *= BETA
+    return x, y, g, 0.0
+
+
+def stopping_exact(theta):
+    return lambda ymin, ynext, gmin, gnext, incmin, inc: ynext >= ymin and gnext >= theta * gmin
+
+
+def stopping_inexact(lam_tol, theta):
+    ex = stopping_exact(theta)
+    return lambda ymin, ynext, gmin, gnext, incmin, inc: inc < lam_tol or ex(ymin, ynext, gmin, gnext, incmin, inc)
+
+
+def newton(F0, F1, F2, x, maxit, stopping_criterion, log=None):
+    y = F0(x)
+    assert math.isfinite(y), "newton: infeasible start"
+    g = F1(x)
+    ymin, gmin, incmin = y, float(np.linalg.norm(g)), math.inf
+    k, converged = 0, False
+    while k < maxit and not converged:
+        k += 1
+        H = F2(x)
+        nstep = solve(H, g)
+        if not amgb_all_isfinite(nstep):
+            break
+        inc = float(np.dot(g, nstep))
+        if inc <= 0:
+            converged = True
+            break
+        xn, yn, gn, s = linesearch_backtracking(x, y, g, nstep, inc, F0, F1)
+        gnn = float(np.linalg.norm(gn))
+        if stopping_criterion(ymin, yn, gmin, gnn, incmin, inc):
+            converged = True
+        x, y, g = xn, yn, gn
+        ymin, gmin, incmin = min(ymin, y), min(gmin, gnn), min(incmin, inc)
+        if log is not None:
+            log.append(dict(k=k, y=y, gnorm=gnn, inc=inc, s=s))
+    return dict(x=x, y=y, k=k, converged=converged)
+
+
+def amgb_step(B: Barrier, M: AMG, z, c, maxit, lam_tol, log=None):
+    """One centering at fixed t (c already scaled by t): Newton on the nested subspaces
+    R[0] (coarsest) ... R[L-1] (finest).  its[l] = Newton steps on level l
+    (docs/src/guide.md:158 `sum(SOL_main.its)`)."""
+    L = len(M.R)
+    its = np.zeros(L, dtype=np.int64)
+    converged = True
+    for J in range(L):
+        R = M.R[J]
+        s0 = np.zeros(R.shape[1])
+        crit = stopping_exact(0.1) if J == L - 1 else stopping_inexact(lam_tol, 0.5)
+        lg = [] if log is not None else None
+        SOL = newton(lambda s: B.f0(s, M.x, M.w, c, R, M.D, z),
+                     lambda s: B.f1(s, M.x, M.w, c, R, M.D, z),
+                     lambda s: B.f2(s, M.x, M.w, c, R, M.D, z),
+                     s0, maxit, crit, lg)
+        its[J] = SOL["k"]
+        if log is not None:
+            log.append(dict(level=J, newton=lg))
+        z = z + R @ SOL["x"]
+        if J == L - 1:
+            converged = SOL["converged"]
+    return dict(z=z, its=its, converged=converged)
+
+
+def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max_newton=None, log=None):
+    if max_newton is None:
+        max_newton = int(math.ceil(math.log2(-math.log2(np.finfo(np.float64).eps)))) + 2 + 40
+    lam_tol = math.sqrt(float(np.min(M.w))) / 2
+    t_begin = time.time()
+    kappa0 = kappa
+    its, ts, cdots = [], [], []
+
+    def cdot(zz):
+        Dz = B.apply_D(M.D, zz)
+        return float(sum(np.dot(M.w * c[:, k], Dz[:, k]) for k in range(len(M.D))))
+
+    SOL = amgb_step(B, M, z, t * c, max_newton, lam_tol, log)
+    if not SOL["converged"]:
+        raise RuntimeError("amgb: initial centering failed at t=%g" % t)
+    z = SOL["z"]
+    its.append(SOL["its"]); ts.append(t); cdots.append(cdot(z))
+    k = 1
+    while t <= 1 / tol and kappa > 1 and k < maxit:
+        k += 1
+        it_k = np.zeros(len(M.R), dtype=np.int64)
+        while kappa > 1:
+            t1 = kappa * t
+            SOL = amgb_step(B, M, z, t1 * c, max_newton, lam_tol, log)
+            it_k += SOL["its"]
+            if SOL["converged"]:
+                if SOL["its"].max() <= max_newton * 0.5:
+                    kappa = min(kappa0, kappa * kappa)
+                z, t = SOL["z"], t1
+                break
+            kappa = math.sqrt(kappa)
+            if kappa < 1 + 1e-3:
+                kappa = 1.0
+        its.append(it_k); ts.append(t); cdots.append(cdot(z))
+    if t <= 1 / tol:
+        raise RuntimeError("amgb: convergence failure at t=%g kappa=%g" % (t, kappa))
+    return dict(z=z, its=np.array(its).T, ts=np.array(ts), c_dot_Dz=np.array(cdots),
+                t_elapsed=time.time() - t_begin)
+
+
+@dataclass
+class AMGBSOL:
+    """src:467-473 field order."""
+    z: np.ndarray
+    SOL_feasibility: Optional[dict]
+    SOL_main: dict
+    log: list
+    geometry: Geometry
+
+
+def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=None, g=None,
+         tol=None, t=0.1, maxit=10000, kappa=10.0, verbose=False, logfile=None, keep_log=False) -> AMGBSOL:
+    dim = geometry.discretization["dim"]
+    f = DEFAULT_F[dim] if f is None else f
+    g = DEFAULT_G[dim] if g is None else g
+    tol = math.sqrt(np.finfo(np.float64).eps) if tol is None else tol
+    M = amg(geometry, state_variables, D)
+    x = M.x
+    z0 = map_rows(lambda xi: g(xi), x)           # (n, S)
+    c = map_rows(lambda xi: f(xi), x)            # (n, K)
+    nD = len(M.D)
+    Q = convex_Euclidian_power(idx=list(range(1, dim + 2)) if nD == dim + 2 else list(range(nD - dim - 1, nD)), p=p)
+    B = Barrier(Q)
+    zvec = z0.reshape(-1, order="F")
+    Dz = B.apply_D(M.D, zvec)
+    if not np.all(np.isfinite(Q.F(x, Dz))):
+        raise NotImplementedError("oracle: feasibility phase not restated (SURVEY §8f-3); start must be strictly feasible")
+    log = [] if keep_log else None
+    SOL = amgb_core(B, M, zvec, c, tol, t=t, maxit=maxit, kappa=kappa, log=log)
+    z = SOL.pop("z").reshape(z0.shape, order="F")
+    return AMGBSOL(z, None, SOL, log or [], geometry)
+
+
+def fem1d_solve(L=4, **kw):
+    return amgb(fem1d(L), **kw)
+
+
+def fem2d_solve(L=2, K=None, **kw):
+    return amgb(fem2d(L, K), **kw)

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def lib():
+    from mgb_amd import _lib
+    return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def gpu_required():
+    import mgb_amd
+    if mgb_amd.device_count() <= 0:
+        pytest.fail("no HIP device visible: -m gpu tests must run on the GPU box (no CPU fallback exists)")
+    return True

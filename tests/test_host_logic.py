@@ -1,0 +1,194 @@
+"""CPU tests (no GPU compute): the C ABI loads and exports every symbol of include/mgb_hip.h, and the
+host-side setup logic of the product (native geometry, level plans, multifrontal Cholesky) agrees with
+the oracle.  These call host-only entry points of the library."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import mgb_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "mgb_hip.h")).read()
+    names = set(re.findall(r"\b(mgb_[A-Za-z0-9_]+)\s*\(", hdr))
+    assert len(names) > 40
+    for n in sorted(names):
+        assert hasattr(lib, n), "libmgb_hip.so does not export %s" % n
+    from mgb_amd import _lib
+    declared = set(_lib.PROTOTYPES) | set(_lib._SPECIAL)
+    assert names == declared, (names ^ declared)
+    assert lib.mgb_version() >= 100
+
+
+def test_no_gpu_fails_loudly(lib):
+    import mgb_amd
+    if mgb_amd.device_count() > 0:
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = lib.mgb_ctx_create(0, C.byref(h))
+    assert rc == -2 and len(lib.mgb_last_error()) > 0          # MGB_E_HIP, never a silent CPU path
+    with pytest.raises(mgb_amd.MGBError):
+        mgb_amd.fem1d_mpi_solve(L=2)
+
+
+def test_argument_errors_are_status_codes(lib):
+    h = C.c_void_p()
+    assert lib.mgb_fem1d_native(0, C.byref(h)) != 0 and b"fem1d" in lib.mgb_last_error()
+    assert lib.mgb_fem2d_native(2, None, 0, None) == -1
+    K = np.zeros((4, 2))
+    assert lib.mgb_fem2d_native(2, K.ctypes.data_as(C.POINTER(C.c_double)), 4, C.byref(h)) != 0
+    assert lib.mgb_geo_matrix_info(None, b"op:dx", None, None, None) == -1
+
+
+def _same_column_space(A, B, tol=1e-12):
+    if A.shape != B.shape:
+        return False
+    f = np.sin(np.arange(A.shape[0]) * 0.7 + 1.0)
+    pa, pb = np.argsort(A.T @ f), np.argsort(B.T @ f)
+    return abs(A[:, pa] - B[:, pb]).max() < tol
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 4])
+def test_native_fem2d_matches_oracle(L):
+    import mgb_amd
+    g, o = mgb_amd.fem2d(L), O.fem2d(L)
+    assert g.x.shape == (14 * 4 ** (L - 1), 2)                 # docs/src/guide.md:246-253
+    assert np.abs(g.x - o.x).max() == 0 and np.abs(g.w - o.w).max() < 1e-15
+    for k in ("id", "dx", "dy"):
+        assert abs(g.operators[k] - o.operators[k]).max() < 1e-13
+    for l in range(L):
+        assert abs(g.refine[l] - o.refine[l]).max() < 1e-14
+        assert abs(g.coarsen[l] - o.coarsen[l]).max() == 0
+        for key in ("full", "dirichlet"):
+            assert _same_column_space(g.subspaces[key][l], o.subspaces[key][l])
+
+
+def test_native_fem2d_custom_mesh():
+    import mgb_amd
+    K = np.array([[0., 0], [2, 0], [0, 1], [2, 0], [2, 1], [0, 1], [2, 0], [3, 0.5], [2, 1]])
+    g, o = mgb_amd.fem2d(2, K), O.fem2d(2, K)
+    assert g.x.shape == (3 * 4 * 7, 2)
+    assert np.abs(g.x - o.x).max() < 1e-15 and abs(g.w.sum() - 2.5) < 1e-13
+    assert abs(g.operators["dx"] - o.operators["dx"]).max() < 1e-13
+    for l in range(2):
+        assert _same_column_space(g.subspaces["dirichlet"][l], o.subspaces["dirichlet"][l])
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 6])
+def test_native_fem1d_matches_oracle(L):
+    import mgb_amd
+    g, o = mgb_amd.fem1d(L), O.fem1d(L)
+    assert g.x.shape == (2 ** (L + 1), 1)
+    assert np.abs(g.x - o.x).max() < 1e-15 and np.abs(g.w - o.w).max() < 1e-16
+    assert abs(g.operators["dx"] - o.operators["dx"]).max() < 1e-12
+    for l in range(L):
+        for key in ("full", "dirichlet"):
+            assert abs(g.subspaces[key][l] - o.subspaces[key][l]).max() < 1e-15
+    if L == 3:
+        assert g.subspaces["dirichlet"][-1].shape == (16, 7)     # test/test_nonsquare.jl:28
+
+
+def _plan(geo_native, state, D, idx, level):
+    """Host-only level plan through the C ABI, from a native geometry (numpy/scipy)."""
+    from mgb_amd import _lib
+    call, dptr, iptr, f64, i32 = _lib.call, _lib.dptr, _lib.iptr, _lib.f64, _lib.i32
+    x = f64(geo_native.x.reshape(geo_native.x.shape[0], -1))
+    w = f64(geo_native.w)
+    Lv = len(geo_native.refine)
+    h = C.c_void_p()
+    call("mgb_geo_create", x.shape[0], x.shape[1], Lv, 1, dptr(x), dptr(w), C.byref(h))
+
+    def put(name, S):
+        S = sp.csr_matrix(S)
+        S.sort_indices()
+        rp, ci, va = i32(S.indptr), i32(S.indices), f64(S.data)
+        call("mgb_geo_set_matrix", h, name.encode(), S.shape[0], S.shape[1], iptr(rp), iptr(ci), dptr(va))
+
+    for k, S in geo_native.operators.items():
+        put("op:" + k, S)
+    for k, v in geo_native.subspaces.items():
+        for l, S in enumerate(v):
+            put("sub:%s:%d" % (k, l), S)
+    iq = (C.c_int * (len(idx) - 1))(*idx[:-1])
+    p = C.c_void_p()
+    call("mgb_plan_create", h, len(state), _lib.str_array(state), len(D), _lib.str_array(D), len(idx) - 1, iq,
+         idx[-1], level, C.byref(p))
+    N, nz, nT, nB = (C.c_int() for _ in range(4))
+    call("mgb_plan_sizes", p, C.byref(N), C.byref(nz), C.byref(nT), C.byref(nB))
+    rp = np.empty(N.value + 1, dtype=np.int32)
+    ci = np.empty(nz.value, dtype=np.int32)
+    call("mgb_plan_pattern", p, iptr(rp), iptr(ci))
+
+    def evaluate(Y):
+        Y = f64(Y)
+        out = np.empty(nz.value)
+        call("mgb_plan_eval_host", p, dptr(Y), dptr(out))
+        Lo = sp.csr_matrix((out, ci, rp), shape=(N.value, N.value))
+        return (Lo + sp.tril(Lo, -1).T).toarray()
+
+    def destroy():
+        call("mgb_plan_destroy", p)
+        call("mgb_geo_destroy", h)
+
+    return N.value, evaluate, destroy
+
+
+def test_hessian_plan_reproduces_reference_recipe_constants():
+    """test/test_matrix_addition.jl:39-95 / test_d0_construction.jl:108-185: constants y11=.5,
+    y12=.1, y22=.3 on D = [dx(u), id(s)] and R = blockdiag(R_dirichlet, R_dirichlet), tol 1e-12."""
+    g = O.fem1d(2)
+    n = g.x.shape[0]
+    # the reference test restricts BOTH state variables with the Dirichlet subspace
+    state = (("u", "dirichlet"), ("s", "dirichlet"))
+    D = (("u", "dx"), ("s", "id"))
+    N, evaluate, destroy = _plan(g, state, D, [0, 1], level=1)
+    Y = np.tile([0.5, 0.1, 0.3], (n, 1)) * g.w[:, None]         # slots (a<=b): (0,0),(0,1),(1,1); Y carries w
+    got = evaluate(Y)
+    Z = sp.csr_matrix((n, n))
+    Dm = [sp.hstack([g.operators["dx"], Z], format="csr"), sp.hstack([Z, g.operators["id"]], format="csr")]
+    y = np.zeros((n, 2, 2))
+    y[:, 0, 0], y[:, 0, 1], y[:, 1, 0], y[:, 1, 1] = 0.5, 0.1, 0.1, 0.3
+    R = sp.block_diag([g.subspaces["dirichlet"][-1]] * 2, format="csr")
+    want = O.hessian_recipe(Dm, g.w, y, R).toarray()
+    destroy()
+    assert got.shape == want.shape == (N, N)
+    assert np.abs(got - want).max() < 1e-12
+    assert np.count_nonzero(got) == np.count_nonzero(want)
+    assert np.allclose(np.linalg.eigvalsh(got), np.linalg.eigvalsh(want), atol=1e-12)
+
+
+@pytest.mark.parametrize("kind,L,level", [("fem1d", 3, 0), ("fem1d", 3, 2), ("fem2d", 2, 0), ("fem2d", 2, 1),
+                                          ("fem2d", 3, 1)])
+def test_hessian_plan_random_y_all_levels(kind, L, level):
+    g = getattr(O, kind)(L)
+    dim = g.discretization["dim"]
+    n = g.x.shape[0]
+    M = O.amg(g)
+    idx = list(range(1, dim + 2))
+    N, evaluate, destroy = _plan(g, O.DEFAULT_STATE, O.DEFAULT_D[dim], idx, level)
+    rng = np.random.default_rng(3)
+    K = len(M.D)
+    A = rng.normal(size=(n, K, K))
+    y = np.einsum("nij,nkj->nik", A, A)                          # SPD per row
+    y[:, 0, :] = 0
+    y[:, :, 0] = 0                                               # the barrier ignores Dz[:,0]
+    slots = [(a, b) for a in range(len(idx)) for b in range(a, len(idx))]
+    Y = np.stack([g.w * y[:, idx[a], idx[b]] for a, b in slots], axis=1)
+    got = evaluate(Y)
+    want = O.hessian_recipe(M.D, g.w, y, M.R[level]).toarray()
+    destroy()
+    assert N == M.R[level].shape[1]
+    assert np.abs(got - want).max() < 1e-12 * max(1.0, np.abs(want).max())
+
+
+def test_multifrontal_cholesky_selftest(lib):
+    r, f, s = C.c_double(), C.c_double(), C.c_double()
+    for nx, ny in ((1, 1), (3, 2), (17, 9), (120, 75)):
+        assert lib.mgb_chol_selftest(nx, ny, C.byref(r), C.byref(f), C.byref(s)) == 0, lib.mgb_last_error()
+        assert r.value < 1e-12
