@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- fem2d p-Laplace multigrid-barrier solve on MI355X (BASELINE.json metric).
+
+A "step" is one full `fem2d_mpi_solve`-equivalent main phase (amgb: t-continuation x level loop x
+Newton) on a geometry + AMG hierarchy already resident in HBM.  value = n * (Newton steps) * K /
+time  ("DoF/s per Newton step", BASELINE.md: DoF := n = rows of x, steps := sum(SOL_main.its)).
+N>1: one process per GPU (torch.distributed over RCCL), each rank solves its own replica of the
+workload this round ("replicas only": the row-block sharded path is not built yet).
+
+One JSON line on rank 0.  Extra objects: `roofline` (dominant HIP kernel, HIP-event timed inside the
+solve on the library's own stream) and `cpu_baseline` (the numpy/scipy oracle timed on the host)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(L, p, budget_s):
+    """Oracle ('port'): Newton steps of amgb_step at t=0.1 on the same mesh, bounded to ~budget_s."""
+    import numpy as np
+    import mgb_oracle as O
+    try:
+        import threadpoolctl
+        cores = threadpoolctl.threadpool_info()
+        cores = max([c.get("num_threads", 1) for c in cores] + [1])
+    except Exception:
+        cores = 1
+    Lc = L
+    g = O.fem2d(Lc)
+    M = O.amg(g)
+    x = M.x
+    z = O.map_rows(lambda xi: O.DEFAULT_G[2](xi), x).reshape(-1, order="F")
+    c = O.map_rows(lambda xi: O.DEFAULT_F[2](xi), x)
+    B = O.Barrier(O.convex_Euclidian_power([1, 2, 3], p))
+    lam_tol = float(np.sqrt(M.w.min()) / 2)
+    steps, t0 = 0, time.time()
+    for J in range(len(M.R)):
+        R = M.R[J]
+        SOL = O.newton(lambda s: B.f0(s, x, M.w, 0.1 * c, R, M.D, z), lambda s: B.f1(s, x, M.w, 0.1 * c, R, M.D, z),
+                       lambda s: B.f2(s, x, M.w, 0.1 * c, R, M.D, z), np.zeros(R.shape[1]), 2,
+                       O.stopping_inexact(lam_tol, 0.5))
+        steps += SOL["k"]
+        z = z + R @ SOL["x"]
+        if time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    n = x.shape[0]
+    return dict(value=n * steps / dt, unit="DoF/s per Newton step", cores=int(cores), kind="port",
+                sample="oracle/mgb_oracle.py: %d Newton steps of amgb_step(t=0.1) on fem2d L=%d p=%g (<=2 per level, "
+                       "coarse->fine, scipy SuperLU solves), %.1f s" % (steps, Lc, p, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--L", type=int, default=7)
+    ap.add_argument("--p", type=float, default=1.0)
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verbose", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    import numpy as np
+    import mgb_amd as M
+
+    if M.device_count() <= 0:
+        raise SystemExit("bench.py: no HIP device visible (the HIP path has no CPU fallback)")
+    dev = local_rank if world > 1 else 0
+    backend = M.backend_hip(dev)
+
+    # ---- setup (untimed): geometry upload + AMG hierarchy resident in HBM
+    t_setup = time.time()
+    geo = M.fem2d_mpi(args.L, backend=backend)
+    A = M.AMG(geo, p=args.p)
+    x = geo.x.to_numpy()
+    z0 = np.vstack([M.DEFAULT_G[2](xi) for xi in x]).reshape(-1, order="F")
+    c = np.vstack([M.DEFAULT_F[2](xi) for xi in x])
+    A.set_c(c)
+    t_setup = time.time() - t_setup
+    n = A.n
+    NL = A.level_size(A.L - 1)[0]
+
+    def one_solve():
+        A.set_z(z0)
+        return A.solve(verbose=args.verbose)
+
+    # preload code objects with a tiny solve (not a warmup step of the workload)
+    small = M.AMG(M.fem2d_mpi(2, backend=backend), p=args.p)
+    xs = small.geometry.x.to_numpy()
+    small.set_c(np.vstack([M.DEFAULT_F[2](xi) for xi in xs]))
+    small.set_z(np.vstack([M.DEFAULT_G[2](xi) for xi in xs]).reshape(-1, order="F"))
+    small.solve()
+    del small
+
+    for _ in range(args.warmup):
+        one_solve()
+
+    def fence():
+        backend.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    fence()
+    t0 = time.perf_counter()
+    sols = [one_solve() for _ in range(args.steps)]
+    backend.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.barrier()
+
+    newton_steps = int(sum(int(s["its"].sum()) for s in sols))
+    value = world * n * newton_steps / elapsed
+    if rank == 0:
+        last = sols[-1]
+        kern = {}
+        for s in sols:
+            for k, v in s["kernels"].items():
+                d = kern.setdefault(k, dict(ms=0.0, bytes=0.0, launches=0))
+                d["ms"] += v["ms"]; d["bytes"] += v["bytes"]; d["launches"] += v["launches"]
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        kd = kern[dom]
+        achieved = kd["bytes"] / max(kd["ms"], 1e-12) / 1e6      # GB/s = bytes / ms / 1e6
+        roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=None,
+                        avg_launch_us=1e3 * kd["ms"] / max(kd["launches"], 1), launches=kd["launches"],
+                        algorithmic_bytes_per_launch=kd["bytes"] / max(kd["launches"], 1),
+                        all_kernels={k: dict(gbs=v["bytes"] / max(v["ms"], 1e-12) / 1e6,
+                                             avg_us=1e3 * v["ms"] / max(v["launches"], 1), launches=v["launches"])
+                                     for k, v in kern.items()})
+        out = {
+            "metric": "fem2d p-Laplace DoF/s per Newton step", "value": value, "unit": "DoF/s per Newton step",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "fem2d p-Laplace L=%d p=%g (n=%d rows, N_L=%d Newton unknowns), amgb main phase, "
+                                   "tol=sqrt(eps)" % (args.L, args.p, n, NL),
+                       "parallelism": "single GPU" if world == 1 else "replicas x%d (not sharded)" % world},
+            "total_solve_s": elapsed / args.steps, "newton_steps_per_solve": newton_steps / args.steps,
+            "host_factor_s_per_solve": sum(s["time_factor"] for s in sols) / args.steps,
+            "gpu_kernel_s_per_solve": sum(v["ms"] for v in kern.values()) / 1e3 / args.steps,
+            "setup_s": t_setup, "t_final": float(last["ts"][-1]), "c_dot_Dz_final": float(last["c_dot_Dz"][-1]),
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.L, args.p, args.cpu_budget)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "mgb_amg_solve": [H, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int],
     "mgb_amg_sol_info": [H, c_int_p, c_dbl_p, c_dbl_p, c_ll_p],
     "mgb_amg_sol_get": [H, c_ll_p, c_dbl_p, c_dbl_p],
+    "mgb_amg_sol_kernels": [H, c_dbl_p, c_dbl_p, c_ll_p],
     "mgb_amg_time_kernels": [H, C.c_int, C.c_int, c_dbl_p, c_dbl_p],
     "mgb_plan_create": [H, C.c_int, c_str_arr, C.c_int, c_str_arr, C.c_int, c_int_p, C.c_int, C.c_int,
                         C.POINTER(H)],

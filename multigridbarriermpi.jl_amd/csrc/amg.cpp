@@ -83,7 +83,7 @@ Csr build_dstack(const GeometryHost& g, const AmgSpec& spec) {
 LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr& Dstack, int level,
                            const BarrierParams& P) {
   LevelPlan pl;
-  const int n = g.n, K = P.K, S = (int)spec.state_variables.size();
+  const int n = g.n, K = P.K;
   std::vector<const Csr*> subs;
   for (auto& sv : spec.state_variables) {
     auto it = g.subspaces.find(sv.second);
@@ -251,8 +251,9 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
   partials_.alloc((size_t)2 * f0_blocks(n_) + 16);
   scal_.alloc(8);
   h_scal_.alloc(8);
-  hip_check(hipMemset(c_.p, 0, c_.n * sizeof(double)), "memset");
-  hip_check(hipMemset(z_.p, 0, z_.n * sizeof(double)), "memset");
+  hip_check(hipMemsetAsync(c_.p, 0, c_.n * sizeof(double), ctx_.stream), "memset");
+  hip_check(hipMemsetAsync(z_.p, 0, z_.n * sizeof(double), ctx_.stream), "memset");
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   const int L = g.L;
   for (int l = 0; l < L; ++l) {
     levels_.emplace_back(new Level);
@@ -288,15 +289,74 @@ void Amg::get_z(double* z_host) {
   z_.download(z_host, (size_t)n_ * S_);
 }
 
+static double csr_bytes(const DevCsr& A, bool y0) {
+  return (double)A.nnz * 12.0 + (A.rows + 1) * 4.0 + A.cols * 8.0 + A.rows * 8.0 * (y0 ? 2 : 1);
+}
+
+KernelTimer::~KernelTimer() {
+  for (auto* v : {&free_, &pending_})
+    for (auto& p : *v) {
+      (void)hipEventDestroy(p.a);
+      (void)hipEventDestroy(p.b);
+    }
+}
+
+void KernelTimer::begin(hipStream_t st, int cls, double bytes) {
+  if (!on_) return;
+  if (free_.empty()) {
+    Pair p{};
+    hip_check(hipEventCreate(&p.a), "hipEventCreate");
+    hip_check(hipEventCreate(&p.b), "hipEventCreate");
+    free_.push_back(p);
+  }
+  cur_ = free_.back();
+  free_.pop_back();
+  cur_.cls = cls;
+  cur_.bytes = bytes;
+  hip_check(hipEventRecord(cur_.a, st), "hipEventRecord");
+  open_ = true;
+}
+
+void KernelTimer::end(hipStream_t st) {
+  if (!on_ || !open_) return;
+  hip_check(hipEventRecord(cur_.b, st), "hipEventRecord");
+  pending_.push_back(cur_);
+  open_ = false;
+}
+
+void KernelTimer::collect(SolveStats& st) {
+  for (auto& p : pending_) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      st.kern_ms[p.cls] += ms;
+      st.kern_bytes[p.cls] += p.bytes;
+      st.kern_launches[p.cls]++;
+    }
+    free_.push_back(p);
+  }
+  pending_.clear();
+}
+
+void Amg::sync_collect(const char* what) {
+  hip_check(hipStreamSynchronize(ctx_.stream), what);
+  if (live_) timer_.collect(*live_);
+}
+
 void Amg::refresh_dz0() { launch_spmv(ctx_.stream, Dstack_.view, z_.p, nullptr, Dz0_.p); }
 
-void Amg::dev_apply(Level& lv, const double* s_dev) { launch_spmv(ctx_.stream, lv.B.view, s_dev, Dz0_.p, Dz_.p); }
+void Amg::dev_apply(Level& lv, const double* s_dev) {
+  timer_.begin(ctx_.stream, KC_APPLY, csr_bytes(lv.B.view, true));
+  launch_spmv(ctx_.stream, lv.B.view, s_dev, Dz0_.p, Dz_.p);
+  timer_.end(ctx_.stream);
+}
 
 double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts) {
   dev_apply(lv, s_dev);
+  timer_.begin(ctx_.stream, KC_F0, (double)n_ * (2 * P_.K + 1) * 8);
   launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, partials_.p, scal_.p);
+  timer_.end(ctx_.stream);
   hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
-  hip_check(hipStreamSynchronize(ctx_.stream), "sync f0");
+  sync_collect("sync f0");
   if (parts) {
     parts[0] = h_scal_.p[0];
     parts[1] = h_scal_.p[1];
@@ -306,22 +366,30 @@ double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts) {
 
 void Amg::dev_f1(Level& lv, const double* s_dev, double t, bool reuse_dz) {
   if (!reuse_dz) dev_apply(lv, s_dev);
+  timer_.begin(ctx_.stream, KC_F1, (double)n_ * (3 * P_.K + 1) * 8);
   launch_barrier_f1(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, t, v_.p);
+  timer_.end(ctx_.stream);
+  timer_.begin(ctx_.stream, KC_RESTRICT, csr_bytes(lv.BT.view, false));
   launch_spmv(ctx_.stream, lv.BT.view, v_.p, nullptr, lv.g.p);
+  timer_.end(ctx_.stream);
   hip_check(hipMemcpyAsync(lv.h_g.p, lv.g.p, (size_t)lv.plan.N * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
             "D2H g");
-  hip_check(hipStreamSynchronize(ctx_.stream), "sync f1");
+  sync_collect("sync f1");
 }
 
 bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st) {
   (void)t;
   const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
   dev_apply(lv, s_dev);
+  timer_.begin(ctx_.stream, KC_F2, (double)n_ * (P_.K + 1 + P_.nY()) * 8);
   launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p);
+  timer_.end(ctx_.stream);
+  timer_.begin(ctx_.stream, KC_ASSEMBLE, csr_bytes(lv.T.view, false));
   launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
+  timer_.end(ctx_.stream);
   hip_check(hipMemcpyAsync(lv.h_avals.p, lv.avals.p, (size_t)nnzA * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
             "D2H avals");
-  hip_check(hipStreamSynchronize(ctx_.stream), "sync f2");
+  sync_collect("sync f2");
   st.n_f2++;
   const double t0 = now_s();
   bool ok = lv.chol.factor(lv.h_avals.p);
@@ -440,6 +508,15 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   const int L = (int)levels_.size();
   st = SolveStats();
   st.L = L;
+  live_ = &st;
+  timer_.enable(opt.time_kernels);
+  struct LiveGuard {
+    Amg* a;
+    ~LiveGuard() {
+      a->live_ = nullptr;
+      a->timer_.enable(false);
+    }
+  } live_guard{this};
   const double t_begin = now_s();
   const double lam_tol = std::sqrt(w_min_) / 2;
   double t = opt.t0, kappa = opt.kappa;
@@ -527,10 +604,6 @@ bool Amg::solve_host(int l, const double* avals, const double* g, double* nstep)
   std::copy(g, g + lv.plan.N, nstep);
   lv.chol.solve(nstep);
   return true;
-}
-
-static double csr_bytes(const DevCsr& A, bool y0) {
-  return (double)A.nnz * 12.0 + (A.rows + 1) * 4.0 + A.cols * 8.0 + A.rows * 8.0 * (y0 ? 2 : 1);
 }
 
 Amg::KernelTimes Amg::time_kernels(int l, int reps) {

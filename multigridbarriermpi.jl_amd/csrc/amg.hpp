@@ -107,6 +107,7 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
                            const BarrierParams& P);
 
 struct SolveOptions {
+  bool time_kernels = true;             // bracket kernels with HIP events (a few us of host time per step)
   double tol = 1.4901161193847656e-08;  // sqrt(eps)
   double t0 = 0.1;
   double kappa = 10.0;
@@ -122,6 +123,31 @@ struct SolveStats {
   double t_elapsed = 0, t_setup = 0;
   double time_factor = 0, time_device = 0;
   long long n_factor = 0, n_f0 = 0, n_f1 = 0, n_f2 = 0;
+  // live HIP-event timing of the six kernel classes over the solve (KernelClass order)
+  double kern_ms[6] = {0, 0, 0, 0, 0, 0};
+  double kern_bytes[6] = {0, 0, 0, 0, 0, 0};
+  long long kern_launches[6] = {0, 0, 0, 0, 0, 0};
+};
+
+enum KernelClass { KC_APPLY = 0, KC_F2 = 1, KC_ASSEMBLE = 2, KC_F1 = 3, KC_RESTRICT = 4, KC_F0 = 5 };
+
+// Event-pair pool: brackets single kernel launches on the context stream; resolved at host syncs.
+class KernelTimer {
+ public:
+  ~KernelTimer();
+  void enable(bool on) { on_ = on; }
+  void begin(hipStream_t st, int cls, double bytes);
+  void end(hipStream_t st);
+  void collect(SolveStats& st);   // call only after the stream has been synchronised
+ private:
+  struct Pair {
+    hipEvent_t a, b;
+    int cls;
+    double bytes;
+  };
+  std::vector<Pair> free_, pending_;
+  Pair cur_{};
+  bool on_ = false, open_ = false;
 };
 
 class Amg {
@@ -189,6 +215,9 @@ class Amg {
   DevBuf<double> w_, c_, z_, z_save_, Dz0_, Dz_, v_, Y_, partials_, scal_;
   PinnedBuf<double> h_scal_;
   double w_min_ = 0;
+  KernelTimer timer_;
+  SolveStats* live_ = nullptr;   // stats object receiving kernel timings during solve()
+  void sync_collect(const char* what);
 };
 
 }  // namespace mgb

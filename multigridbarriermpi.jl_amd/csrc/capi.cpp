@@ -284,7 +284,8 @@ int mgb_vec_create(mgb_ctx ctx, int n, const double* host, mgb_vec* out) {
     try {
       v->buf.alloc(n);
       if (host) v->buf.upload(host, n);
-      else if (n) hip_check(hipMemset(v->buf.p, 0, (size_t)n * sizeof(double)), "memset");
+      else if (n)  // stream-ordered: a null-stream memset is not ordered against the non-blocking context stream
+        hip_check(hipMemsetAsync(v->buf.p, 0, (size_t)n * sizeof(double), ctx->ctx.stream), "memset");
     } catch (...) {
       delete v;
       throw;
@@ -536,6 +537,16 @@ int mgb_amg_sol_get(mgb_amg a, long long* its, double* ts, double* c_dot_Dz) {
     if (its) std::copy(a->stats.its.begin(), a->stats.its.end(), its);
     if (ts) std::copy(a->stats.ts.begin(), a->stats.ts.end(), ts);
     if (c_dot_Dz) std::copy(a->stats.c_dot_Dz.begin(), a->stats.c_dot_Dz.end(), c_dot_Dz);
+  });
+}
+int mgb_amg_sol_kernels(mgb_amg a, double* ms6, double* bytes6, long long* launches6) {
+  return guard([&] {
+    need(a, "null amg");
+    for (int i = 0; i < 6; ++i) {
+      if (ms6) ms6[i] = a->stats.kern_ms[i];
+      if (bytes6) bytes6[i] = a->stats.kern_bytes[i];
+      if (launches6) launches6[i] = a->stats.kern_launches[i];
+    }
   });
 }
 int mgb_amg_time_kernels(mgb_amg a, int level, int reps, double* ms6, double* bytes6) {
