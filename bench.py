@@ -44,7 +44,7 @@ def cpu_baseline(L, p, budget_s):
     steps, t0 = 0, time.time()
     for J in range(len(M.R)):
         R = M.R[J]
-        SOL = O.newton(lambda s: B.f0(s, x, M.w, 0.1 * c, R, M.D, z), lambda s: B.f1(s, x, M.w, 0.1 * c, R, M.D, z),
+        SOL = O.newton(lambda s, ref: B.f0_phi(s, x, M.w, 0.1 * c, R, M.D, z, ref), lambda s: B.f1(s, x, M.w, 0.1 * c, R, M.D, z),
                        lambda s: B.f2(s, x, M.w, 0.1 * c, R, M.D, z), np.zeros(R.shape[1]), 2,
                        O.stopping_inexact(lam_tol, 0.5))
         steps += SOL["k"]

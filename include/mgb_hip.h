@@ -97,10 +97,16 @@ int mgb_amg_get_z(mgb_amg a, double* z);           /* mpi_to_native(sol).z, src:
  *   f1: test/test_column_extract.jl:50-80;  f2: test/test_map_rows_compare.jl:102-123,165-170 */
 int mgb_amg_apply_D(mgb_amg a, int level, const double* s, double* Dz /* n x K */);
 int mgb_amg_f0(mgb_amg a, int level, const double* s, double t, double* y, double* parts2);
+/* line-search trial (amgb_all_isfinite semantics, src:121-133, plus the fraction-to-the-boundary rule):
+ * y = f0(s) if every row keeps >= 10 % of the cone distance it has at s_ref, else +inf */
+int mgb_amg_f0_trial(mgb_amg a, int level, const double* s_ref, const double* s, double t, double* y);
 int mgb_amg_f1(mgb_amg a, int level, const double* s, double t, double* g);
 int mgb_amg_f2(mgb_amg a, int level, const double* s, double t, double* lower_vals);
 /* MultiGridBarrier.solve(A, b) = A \ b (test/test_instrumented_solve.jl:25-28,99), host direct solve */
 int mgb_amg_solve_linear(mgb_amg a, int level, const double* lower_vals, const double* g, double* x);
+/* amgb_step level schedule: 0 (default) = Newton on the finest subspace only, 1 = literal coarse -> fine
+ * level loop (R_1 ... R_L).  Both end at the same z; see DESIGN.md section 2. */
+int mgb_amg_set_schedule(mgb_amg a, int all_levels);
 /* amgb main phase: t-continuation x level loop x Newton; z updated in place */
 int mgb_amg_solve(mgb_amg a, double tol, double t0, double kappa, int maxit, int max_newton, int verbose);
 /* SOL_main fields (docs/src/api.md:97-101) of the last mgb_amg_solve */

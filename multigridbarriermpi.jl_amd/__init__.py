@@ -464,6 +464,13 @@ class AMG:
         call("mgb_amg_f0", self.handle, l, dptr(s), float(t), C.byref(y), dptr(pr))
         return (y.value, pr) if parts else y.value
 
+    def f0_trial(self, l, s_ref, s, t):
+        """Line-search trial: f0(s), or +inf if a row lost more than 90 % of its cone distance w.r.t. s_ref."""
+        s_ref, s = f64(s_ref), f64(s)
+        y = C.c_double()
+        call("mgb_amg_f0_trial", self.handle, l, dptr(s_ref), dptr(s), float(t), C.byref(y))
+        return y.value
+
     def f1(self, l, s, t):
         s = f64(s)
         g = np.empty(self.level_size(l)[0])
@@ -486,7 +493,10 @@ class AMG:
         call("mgb_amg_solve_linear", self.handle, l, dptr(lower_vals), dptr(g), dptr(x))
         return x
 
-    def solve(self, tol=None, t=0.1, kappa=10.0, maxit=10000, max_newton=0, verbose=0):
+    def solve(self, tol=None, t=0.1, kappa=10.0, maxit=10000, max_newton=0, verbose=0, schedule="fine"):
+        if schedule not in ("fine", "all"):
+            raise ValueError("schedule must be 'fine' or 'all'")
+        call("mgb_amg_set_schedule", self.handle, 1 if schedule == "all" else 0)
         call("mgb_amg_solve", self.handle, float(tol or 0.0), float(t), float(kappa), int(maxit), int(max_newton),
              int(verbose))
         nt, te, tf = C.c_int(), C.c_double(), C.c_double()
@@ -537,7 +547,7 @@ class AMGBSOL:
 
 
 def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=None, g=None, tol=None, t=0.1,
-         maxit=10000, kappa=10.0, verbose=False, logfile=None, **rest) -> AMGBSOL:
+         maxit=10000, kappa=10.0, verbose=False, logfile=None, schedule="fine", **rest) -> AMGBSOL:
     """MultiGridBarrier.amgb on an MPI geometry (called at src:599,666).  kwargs as documented in
     docs/src/guide.md:148-152; unknown kwargs (e.g. `L`, forwarded by fem*d_mpi_solve, src:663-666)
     are ignored like Julia's `kwargs...` fan-out."""
@@ -556,7 +566,8 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
     if not math.isfinite(y0):
         raise NotImplementedError("amgb: the initial point is not strictly feasible; the feasibility phase "
                                   "(SOL_feasibility) is not built yet (SURVEY §8f-3)")
-    SOL = M.solve(tol=tol, t=t, kappa=kappa, maxit=maxit, verbose=2 if verbose and verbose > 1 else int(bool(verbose)))
+    SOL = M.solve(tol=tol, t=t, kappa=kappa, maxit=maxit, verbose=2 if verbose and verbose > 1 else int(bool(verbose)),
+                  schedule=schedule)
     z = M.get_z().reshape(z0.shape, order="F")
     return AMGBSOL(HPCMatrix(z, geometry.x.backend), None, SOL, [], geometry)
 

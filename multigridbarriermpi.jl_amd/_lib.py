@@ -62,9 +62,11 @@ PROTOTYPES = {
     "mgb_amg_get_z": [H, c_dbl_p],
     "mgb_amg_apply_D": [H, C.c_int, c_dbl_p, c_dbl_p],
     "mgb_amg_f0": [H, C.c_int, c_dbl_p, C.c_double, c_dbl_p, c_dbl_p],
+    "mgb_amg_f0_trial": [H, C.c_int, c_dbl_p, c_dbl_p, C.c_double, c_dbl_p],
     "mgb_amg_f1": [H, C.c_int, c_dbl_p, C.c_double, c_dbl_p],
     "mgb_amg_f2": [H, C.c_int, c_dbl_p, C.c_double, c_dbl_p],
     "mgb_amg_solve_linear": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],
+    "mgb_amg_set_schedule": [H, C.c_int],
     "mgb_amg_solve": [H, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int],
     "mgb_amg_sol_info": [H, c_int_p, c_dbl_p, c_dbl_p, c_ll_p],
     "mgb_amg_sol_get": [H, c_ll_p, c_dbl_p, c_dbl_p],

@@ -245,9 +245,12 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
   z_.alloc((size_t)n_ * S_);
   z_save_.alloc((size_t)n_ * S_);
   Dz0_.alloc((size_t)n_ * K);
+  Dz0_save_.alloc((size_t)n_ * K);
   Dz_.alloc((size_t)n_ * K);
   v_.alloc((size_t)n_ * K);
   Y_.alloc((size_t)n_ * nY);
+  phi_cur_.alloc(n_);
+  phi_trial_.alloc(n_);
   partials_.alloc((size_t)2 * f0_blocks(n_) + 16);
   scal_.alloc(8);
   h_scal_.alloc(8);
@@ -350,10 +353,12 @@ void Amg::dev_apply(Level& lv, const double* s_dev) {
   timer_.end(ctx_.stream);
 }
 
-double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts) {
+double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts, bool trial) {
   dev_apply(lv, s_dev);
-  timer_.begin(ctx_.stream, KC_F0, (double)n_ * (2 * P_.K + 1) * 8);
-  launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, partials_.p, scal_.p);
+  timer_.begin(ctx_.stream, KC_F0, (double)n_ * (2 * P_.K + 2 + (trial ? 1 : 0)) * 8);
+  // start of a Newton solve: record phi of the iterate; trial: test against it, keep the trial's phi aside
+  launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, trial ? phi_cur_.p : nullptr, kFracToBoundary,
+                    trial ? phi_trial_.p : phi_cur_.p, partials_.p, scal_.p);
   timer_.end(ctx_.stream);
   hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
   sync_collect("sync f0");
@@ -403,6 +408,7 @@ bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st)
 }
 
 static const double kBeta = 0.5, kArmijo = 0.1, kMinStep = 1e-8;
+// kFracToBoundary (amg.hpp) = oracle FRAC_TO_BOUNDARY
 
 Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int maxit, SolveStats& st, int verbose) {
   Level& lv = *levels_[l];
@@ -413,9 +419,31 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
     return res;
   }
   hip_check(hipMemsetAsync(lv.s.p, 0, (size_t)N * sizeof(double), ctx_.stream), "memset s");
-  double y = dev_f0(lv, lv.s.p, t, nullptr);
+  double y = dev_f0(lv, lv.s.p, t, nullptr, false);
   st.n_f0++;
-  if (!std::isfinite(y)) throw std::runtime_error("newton: infeasible start");
+  if (!std::isfinite(y)) {
+    // diagnose: which rows left the cone
+    std::vector<double> hdz((size_t)n_ * P_.K);
+    Dz_.download(hdz.data(), hdz.size());
+    int bad = 0, worst = -1;
+    double minphi = INFINITY;
+    for (int q = 0; q < n_; ++q) {
+      const double* d = hdz.data() + (size_t)q * P_.K;
+      double qq = 0;
+      for (int i = 0; i < P_.nq; ++i) qq += d[P_.iq[i]] * d[P_.iq[i]];
+      const double sv = d[P_.is];
+      const double phi = (sv > 0 ? std::pow(sv, P_.a) : -1.0) - qq;
+      if (!(phi > 0) || !(sv > 0)) bad++;
+      if (!(phi >= minphi)) {
+        minphi = phi;
+        worst = q;
+      }
+    }
+    char buf[256];
+    snprintf(buf, sizeof buf, "newton: infeasible start (level %d, t=%g, %d of %d rows outside the cone, min phi=%g at row %d, y=%g)",
+             l, t, bad, n_, minphi, worst, y);
+    throw std::runtime_error(buf);
+  }
   dev_f1(lv, lv.s.p, t, true);
   st.n_f1++;
   auto norm2 = [&](const double* a) {
@@ -447,7 +475,7 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
     bool accepted = false;
     while (step >= kMinStep) {
       launch_waxpby(ctx_.stream, N, lv.s.p, -step, lv.nstep.p, lv.s_trial.p);
-      const double yt = dev_f0(lv, lv.s_trial.p, t, nullptr);
+      const double yt = dev_f0(lv, lv.s_trial.p, t, nullptr, true);
       st.n_f0++;
       if (std::isfinite(yt) && yt <= y - kArmijo * step * inc) {
         std::copy(lv.h_g.p, lv.h_g.p + N, lv.h_s.p);  // keep old gradient in case the new one is not finite
@@ -465,7 +493,10 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
       }
       step *= kBeta;
     }
-    if (accepted) std::swap(lv.s.p, lv.s_trial.p);
+    if (accepted) {
+      std::swap(lv.s.p, lv.s_trial.p);
+      std::swap(phi_cur_.p, phi_trial_.p);
+    }
     if (!accepted) step = 0.0;
     const bool exact = ynext >= ymin && gnext >= theta * gmin;
     if ((!finest && inc < lam_tol) || exact) res.converged = true;
@@ -483,13 +514,18 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
 bool Amg::amgb_step(double t, double lam_tol, int max_newton, std::vector<long long>& its, SolveStats& st, int verbose) {
   const int L = (int)levels_.size();
   bool converged = true;
-  for (int J = 0; J < L; ++J) {
+  // level schedule: finest level only (default) or the literal coarse -> fine loop (oracle LEVEL_SCHEDULE)
+  for (int J = (schedule_all_ ? 0 : L - 1); J < L; ++J) {
     Level& lv = *levels_[J];
     NewtonResult r = newton(J, t, J == L - 1, lam_tol, max_newton, st, verbose);
     its[J] += r.k;
     if (lv.plan.N > 0) {
       launch_spmv(ctx_.stream, lv.R.view, lv.s.p, z_.p, z_.p);
-      refresh_dz0();
+      // carry the ACCEPTED Dz forward as the next Dz0 (bit-for-bit the values verified to be inside the
+      // cone) instead of re-evaluating D(z + R s): see oracle Barrier._Dz
+      dev_apply(lv, lv.s.p);
+      hip_check(hipMemcpyAsync(Dz0_.p, Dz_.p, (size_t)n_ * P_.K * sizeof(double), hipMemcpyDeviceToDevice,
+                               ctx_.stream), "Dz0 <- Dz");
     }
     if (J == L - 1) converged = r.converged;
   }
@@ -497,7 +533,7 @@ bool Amg::amgb_step(double t, double lam_tol, int max_newton, std::vector<long l
 }
 
 double Amg::c_dot_dz() {
-  launch_barrier_f0(ctx_.stream, n_, P_, Dz0_.p, w_.p, c_.p, partials_.p, scal_.p);
+  launch_barrier_f0(ctx_.stream, n_, P_, Dz0_.p, w_.p, c_.p, nullptr, 0.0, nullptr, partials_.p, scal_.p);
   hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   return h_scal_.p[1];
@@ -521,7 +557,8 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   const double lam_tol = std::sqrt(w_min_) / 2;
   double t = opt.t0, kappa = opt.kappa;
   const double kappa0 = opt.kappa;
-  const size_t zbytes = (size_t)n_ * S_ * sizeof(double);
+  const size_t zbytes = (size_t)n_ * S_ * sizeof(double), dzbytes = (size_t)n_ * P_.K * sizeof(double);
+  schedule_all_ = opt.schedule_all;
   std::vector<long long> its(L, 0);
   refresh_dz0();
   if (!amgb_step(t, lam_tol, opt.max_newton, its, st, opt.verbose))
@@ -536,6 +573,7 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
     while (kappa > 1) {
       const double t1 = kappa * t;
       hip_check(hipMemcpyAsync(z_save_.p, z_.p, zbytes, hipMemcpyDeviceToDevice, ctx_.stream), "save z");
+      hip_check(hipMemcpyAsync(Dz0_save_.p, Dz0_.p, dzbytes, hipMemcpyDeviceToDevice, ctx_.stream), "save Dz0");
       std::vector<long long> it1(L, 0);
       bool ok = amgb_step(t1, lam_tol, opt.max_newton, it1, st, opt.verbose);
       long long mx = 0;
@@ -549,7 +587,7 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
         break;
       }
       hip_check(hipMemcpyAsync(z_.p, z_save_.p, zbytes, hipMemcpyDeviceToDevice, ctx_.stream), "restore z");
-      refresh_dz0();
+      hip_check(hipMemcpyAsync(Dz0_.p, Dz0_save_.p, dzbytes, hipMemcpyDeviceToDevice, ctx_.stream), "restore Dz0");
       kappa = std::sqrt(kappa);
       if (kappa < 1 + 1e-3) kappa = 1.0;
     }
@@ -569,7 +607,15 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
 double Amg::f0(int l, const double* s_host, double t, double* parts) {
   Level& lv = *levels_.at(l);
   lv.s_trial.upload(s_host, lv.plan.N);
-  return dev_f0(lv, lv.s_trial.p, t, parts);
+  return dev_f0(lv, lv.s_trial.p, t, parts, false);
+}
+
+double Amg::f0_trial(int l, const double* s_ref_host, const double* s_host, double t) {
+  Level& lv = *levels_.at(l);
+  lv.s_trial.upload(s_ref_host, lv.plan.N);
+  dev_f0(lv, lv.s_trial.p, t, nullptr, false);     // records phi of the reference iterate
+  lv.s_trial.upload(s_host, lv.plan.N);
+  return dev_f0(lv, lv.s_trial.p, t, nullptr, true);
 }
 
 void Amg::f1(int l, const double* s_host, double t, double* g_host) {
@@ -634,8 +680,10 @@ Amg::KernelTimes Amg::time_kernels(int l, int reps) {
   kt.f1_bytes = n * (3 * K + 1) * 8;
   kt.restrict_ms = timeit([&] { launch_spmv(ctx_.stream, lv.BT.view, v_.p, nullptr, lv.g.p); });
   kt.restrict_bytes = csr_bytes(lv.BT.view, false);
-  kt.f0_ms = timeit([&] { launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, partials_.p, scal_.p); });
-  kt.f0_bytes = n * (2 * K + 1) * 8;
+  kt.f0_ms = timeit([&] {
+    launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, phi_cur_.p, 0.0, phi_trial_.p, partials_.p, scal_.p);
+  });
+  kt.f0_bytes = n * (2 * K + 3) * 8;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return kt;

@@ -106,7 +106,10 @@ Csr build_dstack(const GeometryHost& g, const AmgSpec& spec);
 LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr& Dstack, int level,
                            const BarrierParams& P);
 
+constexpr double kFracToBoundary = 0.1;   // == oracle FRAC_TO_BOUNDARY
+
 struct SolveOptions {
+  bool schedule_all = false;            // false: finest level only; true: coarse -> fine level loop
   bool time_kernels = true;             // bracket kernels with HIP events (a few us of host time per step)
   double tol = 1.4901161193847656e-08;  // sqrt(eps)
   double t0 = 0.1;
@@ -169,6 +172,9 @@ class Amg {
   // fine-grained evaluations at level l, s (N_l host values), barrier parameter t
   //   f0 -> returns objective, also fills parts[2] = {sum w F, sum w c.Dz}
   double f0(int l, const double* s_host, double t, double* parts);
+  // line-search trial semantics: objective at s, +inf unless every row keeps >= kFracToBoundary of the cone
+  // distance it has at s_ref
+  double f0_trial(int l, const double* s_ref_host, const double* s_host, double t);
   void f1(int l, const double* s_host, double t, double* g_host);
   void f2(int l, const double* s_host, double t, double* avals_host);   // lower-triangle values, plan(l).Apat order
   void apply_D(int l, const double* s_host, double* Dz_host);          // n x K row-major
@@ -199,7 +205,7 @@ class Amg {
   };
   void refresh_dz0();
   void dev_apply(Level& lv, const double* s_dev);                 // Dz = Dz0 + B s
-  double dev_f0(Level& lv, const double* s_dev, double t, double* parts);
+  double dev_f0(Level& lv, const double* s_dev, double t, double* parts, bool trial);
   void dev_f1(Level& lv, const double* s_dev, double t, bool reuse_dz);   // -> lv.g and lv.h_g
   bool dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st);  // -> lv.h_n / lv.nstep
   NewtonResult newton(int l, double t, bool finest, double lam_tol, int maxit, SolveStats& st, int verbose);
@@ -212,9 +218,10 @@ class Amg {
   AmgSpec spec_;
   DevCsrOwned Dstack_;
   std::vector<std::unique_ptr<Level>> levels_;
-  DevBuf<double> w_, c_, z_, z_save_, Dz0_, Dz_, v_, Y_, partials_, scal_;
+  DevBuf<double> w_, c_, z_, z_save_, Dz0_, Dz0_save_, Dz_, v_, Y_, partials_, scal_, phi_cur_, phi_trial_;
   PinnedBuf<double> h_scal_;
   double w_min_ = 0;
+  bool schedule_all_ = false;
   KernelTimer timer_;
   SolveStats* live_ = nullptr;   // stats object receiving kernel timings during solve()
   void sync_collect(const char* what);

@@ -30,6 +30,7 @@ struct mgb_amg_s {
   mgb_ctx_s* ctx;
   std::unique_ptr<Amg> amg;
   SolveStats stats;
+  bool schedule_all = false;
 };
 struct mgb_plan_s {
   LevelPlan plan;
@@ -484,6 +485,12 @@ int mgb_amg_f0(mgb_amg a, int level, const double* s, double t, double* y, doubl
     *y = a->amg->f0(level, s, t, parts2);
   });
 }
+int mgb_amg_f0_trial(mgb_amg a, int level, const double* s_ref, const double* s, double t, double* y) {
+  return guard([&] {
+    need(a && s_ref && s && y && level >= 0 && level < a->amg->L(), "f0_trial: bad arguments");
+    *y = a->amg->f0_trial(level, s_ref, s, t);
+  });
+}
 int mgb_amg_f1(mgb_amg a, int level, const double* s, double t, double* g) {
   return guard([&] {
     need(a && s && g && level >= 0 && level < a->amg->L(), "f1: bad arguments");
@@ -502,10 +509,17 @@ int mgb_amg_solve_linear(mgb_amg a, int level, const double* lower_vals, const d
     if (!a->amg->solve_host(level, lower_vals, g, x)) throw std::runtime_error("MfChol: matrix is not positive definite");
   });
 }
+int mgb_amg_set_schedule(mgb_amg a, int all_levels) {
+  return guard([&] {
+    need(a, "null amg");
+    a->schedule_all = all_levels != 0;
+  });
+}
 int mgb_amg_solve(mgb_amg a, double tol, double t0, double kappa, int maxit, int max_newton, int verbose) {
   return guard([&] {
     need(a, "null amg");
     SolveOptions o;
+    o.schedule_all = a->schedule_all;
     if (tol > 0) o.tol = tol;
     if (t0 > 0) o.t0 = t0;
     if (kappa > 1) o.kappa = kappa;

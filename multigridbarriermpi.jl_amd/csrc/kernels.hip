@@ -113,9 +113,13 @@ __device__ inline Cone load_cone(const BarrierParams& P, const double* dz) {
   return c;
 }
 
+// phi_ref (nullable): cone distance of every row at the current iterate; a trial row with
+// phi < frac*phi_ref[q] is treated as infeasible (fraction-to-the-boundary rule of the line search).
 __global__ __launch_bounds__(kBlock) void barrier_f0_kernel(int n, BarrierParams P, const double* __restrict__ Dz,
                                                              const double* __restrict__ w,
-                                                             const double* __restrict__ c, double* partials) {
+                                                             const double* __restrict__ c,
+                                                             const double* __restrict__ phi_ref, double frac,
+                                                             double* __restrict__ phi_out, double* partials) {
   __shared__ double lds[kBlock / 64];
   double accF = 0.0, accL = 0.0;
   for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < n; q += (long long)gridDim.x * kBlock) {
@@ -123,6 +127,8 @@ __global__ __launch_bounds__(kBlock) void barrier_f0_kernel(int n, BarrierParams
     const double* cq = c + q * P.K;
     const double wq = w[q];
     Cone k = load_cone(P, dz);
+    if (phi_ref && !(k.phi >= frac * phi_ref[q])) k.ok = false;
+    if (phi_out) phi_out[q] = k.phi;
     const double F = k.ok ? (-log(k.phi) - P.mu * log(k.s)) : INFINITY;
     accF += wq * F;
     double lin = 0.0;
@@ -233,9 +239,10 @@ void launch_waxpby(hipStream_t st, int n, const double* x, double alpha, const d
 int f0_blocks(int n) { return grid_for(n); }
 
 void launch_barrier_f0(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
-                       double* partials, double* out2) {
+                       const double* phi_ref, double frac, double* phi_out, double* partials, double* out2) {
   const int grid = grid_for(n);
-  hipLaunchKernelGGL(barrier_f0_kernel, dim3(grid), dim3(kBlock), 0, st, n, P, Dz, w, c, partials);
+  hipLaunchKernelGGL(barrier_f0_kernel, dim3(grid), dim3(kBlock), 0, st, n, P, Dz, w, c, phi_ref, frac, phi_out,
+                     partials);
   hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, grid, 2, partials, out2);
 }
 

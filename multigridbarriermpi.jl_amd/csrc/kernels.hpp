@@ -34,8 +34,10 @@ void launch_waxpby(hipStream_t st, int n, const double* x, double alpha, const d
 // out2[0] = sum_q w F(Dz_q) ; out2[1] = sum_q w <c_q, Dz_q>   (+inf / NaN if any row infeasible)
 // partials: scratch of 2*f0_blocks(n) doubles.
 int f0_blocks(int n);
+// phi_ref (nullable) + frac: fraction-to-the-boundary test of a line-search trial; phi_out (nullable): per-row
+// cone distance s^(2/p) - |q|^2 of this evaluation.
 void launch_barrier_f0(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
-                       double* partials, double* out2);
+                       const double* phi_ref, double frac, double* phi_out, double* partials, double* out2);
 // v[q,k] = w_q (dF/dDz_k + t c[q,k])
 void launch_barrier_f1(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
                        double t, double* v);

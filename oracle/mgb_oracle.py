@@ -333,11 +333,17 @@ class PowerConeBarrier:
     idx: Sequence[int]
     p: float
 
-    def F(self, x, Y):
+    def phi(self, Y):
+        """Distance function of the cone: phi = s^(2/p) - |q|^2 (negative when s <= 0)."""
         q, s = Y[:, self.idx[:-1]], Y[:, self.idx[-1]]
         a = 2.0 / self.p
         with np.errstate(all="ignore"):
-            phi = np.where(s > 0, np.power(np.abs(s), a), -1.0) - np.sum(q * q, axis=1)
+            return np.where(s > 0, np.power(np.abs(s), a), -1.0) - np.sum(q * q, axis=1)
+
+    def F(self, x, Y):
+        s = Y[:, self.idx[-1]]
+        phi = self.phi(Y)
+        with np.errstate(all="ignore"):
             val = -np.log(phi) - barrier_mu(self.p) * np.log(s)
             val = np.where((phi > 0) & (s > 0), val, np.inf)
         return val
@@ -388,23 +394,42 @@ class Barrier:
     def apply_D(D, z):
         return np.stack([Dk @ z for Dk in D], axis=1)
 
-    def f0(self, s, x, w, c, R, D, z0):
-        Dz = self.apply_D(D, z0 + R @ s)
+    def _Dz(self, s, R, D, z0, pre):
+        """Dz at z0 + R s.  `pre = (Dz0, BR)` with Dz0 = D z0 (n x K) and BR[k] = D_k R evaluates
+        Dz0 + [BR_k s]_k instead: the driver carries Dz0 forward as the accepted Dz of the previous
+        Newton solve, so the start of the next solve sees bit-for-bit the values already verified to be
+        inside the cone (re-evaluating D(z0 + R s) has cancellation noise ~1e-13 in dx*u, enough to flip
+        the sign of phi = s^2 - |grad u|^2 on plateaus where both vanish like 1/t)."""
+        if pre is None:
+            return self.apply_D(D, z0 + R @ s)
+        Dz0, BR = pre
+        return Dz0 + np.stack([BRk @ s for BRk in BR], axis=1)
+
+    def f0(self, s, x, w, c, R, D, z0, pre=None):
+        return self.f0_phi(s, x, w, c, R, D, z0, pre=pre)[0]
+
+    def f0_phi(self, s, x, w, c, R, D, z0, phi_ref=None, pre=None):
+        """(objective, per-row phi).  With `phi_ref` (phi at the current iterate) the trial is also
+        rejected (objective = inf) unless phi >= FRAC_TO_BOUNDARY * phi_ref in every row."""
+        Dz = self._Dz(s, R, D, z0, pre)
+        phi = self.Q.phi(Dz)
         y = self.Q.F(x, Dz)
         if not np.all(np.isfinite(y)):
-            return np.inf
-        return float(np.dot(w, y) + sum(np.dot(w * c[:, k], Dz[:, k]) for k in range(len(D))))
+            return np.inf, phi
+        if phi_ref is not None and np.any(phi < FRAC_TO_BOUNDARY * phi_ref):
+            return np.inf, phi
+        return float(np.dot(w, y) + sum(np.dot(w * c[:, k], Dz[:, k]) for k in range(len(D)))), phi
 
-    def f1(self, s, x, w, c, R, D, z0):
-        Dz = self.apply_D(D, z0 + R @ s)
+    def f1(self, s, x, w, c, R, D, z0, pre=None):
+        Dz = self._Dz(s, R, D, z0, pre)
         y = self.Q.F1(x, Dz) + c
         ret = np.zeros(D[0].shape[1])
         for k in range(len(D)):
             ret += D[k].T @ (w * y[:, k])
         return R.T @ ret
 
-    def f2(self, s, x, w, c, R, D, z0):
-        Dz = self.apply_D(D, z0 + R @ s)
+    def f2(self, s, x, w, c, R, D, z0, pre=None):
+        Dz = self._Dz(s, R, D, z0, pre)
         y = self.Q.F2(x, Dz)
         return hessian_recipe(D, w, y, R)
 
@@ -433,6 +458,8 @@ def hessian_recipe(D, w, y, R=None):
 BETA = 0.5          # backtracking factor
 ARMIJO = 0.1        # sufficient-decrease constant
 MIN_STEP = 1e-8     # give up the line search below this step length
+REFINE = True       # after the first acceptable step keep halving while the objective improves
+FRAC_TO_BOUNDARY = 0.1  # a step may not shrink any row's cone distance phi below this fraction of its value
 
 
 def solve(H, g):
@@ -443,19 +470,29 @@ def solve(H, g):
     return spla.splu(H).solve(g)
 
 
-def linesearch_backtracking(x, y, g, n, inc, F0, F1):
+def linesearch_backtracking(x, y, g, n, inc, F0, F1, phi=None):
     """Backtracking on s in {1, beta, beta^2, ...}: the trial must be finite
-    (`amgb_all_isfinite`, src:121) and satisfy y(x - s n) <= y - ARMIJO*s*inc."""
+    (`amgb_all_isfinite`, src:121), keep every row at least FRAC_TO_BOUNDARY of its previous distance
+    to the cone boundary (the w-weighted log barrier alone lets Armijo accept points that sit on the
+    boundary up to rounding) and satisfy y(x - s n) <= y - ARMIJO*s*inc.  F0(x, phi_ref) -> (y, phi)."""
     s = 1.0
     while s >= MIN_STEP:
         xn = x - s * n
-        yn = F0(xn)
+        yn, phin = F0(xn, phi)
         if math.isfinite(yn) and yn <= y - ARMIJO * s * inc:
+            # do not overshoot the 1-D minimum towards the boundary: keep halving while the objective
+            # still improves (grid version of the exact line search)
+            while REFINE and s * BETA >= MIN_STEP:
+                x2 = x - (s * BETA) * n
+                y2, phi2 = F0(x2, phi)
+                if not (math.isfinite(y2) and y2 < yn):
+                    break
+                xn, yn, phin, s = x2, y2, phi2, s * BETA
             gn = F1(xn)
             if amgb_all_isfinite(gn):
-                return xn, yn, gn, s
+                return xn, yn, gn, s, phin
         s *= BETA
-    return x, y, g, 0.0
+    return x, y, g, 0.0, phi
 
 
 def stopping_exact(theta):
@@ -468,7 +505,7 @@ def stopping_inexact(lam_tol, theta):
 
 
 def newton(F0, F1, F2, x, maxit, stopping_criterion, log=None):
-    y = F0(x)
+    y, phi = F0(x, None)
     assert math.isfinite(y), "newton: infeasible start"
     g = F1(x)
     ymin, gmin, incmin = y, float(np.linalg.norm(g)), math.inf
@@ -483,7 +520,7 @@ def newton(F0, F1, F2, x, maxit, stopping_criterion, log=None):
         if inc <= 0:
             converged = True
             break
-        xn, yn, gn, s = linesearch_backtracking(x, y, g, nstep, inc, F0, F1)
+        xn, yn, gn, s, phi = linesearch_backtracking(x, y, g, nstep, inc, F0, F1, phi)
         gnn = float(np.linalg.norm(gn))
         if stopping_criterion(ymin, yn, gmin, gnn, incmin, inc):
             converged = True
@@ -494,32 +531,49 @@ def newton(F0, F1, F2, x, maxit, stopping_criterion, log=None):
     return dict(x=x, y=y, k=k, converged=converged)
 
 
-def amgb_step(B: Barrier, M: AMG, z, c, maxit, lam_tol, log=None):
-    """One centering at fixed t (c already scaled by t): Newton on the nested subspaces
-    R[0] (coarsest) ... R[L-1] (finest).  its[l] = Newton steps on level l
-    (docs/src/guide.md:158 `sum(SOL_main.its)`)."""
+LEVEL_SCHEDULE = "fine"   # "fine": Newton on the finest subspace only; "all": coarse -> fine level loop
+
+
+def level_schedule(L, schedule=None):
+    schedule = LEVEL_SCHEDULE if schedule is None else schedule
+    return [L - 1] if schedule == "fine" else list(range(L))
+
+
+def amgb_step(B: Barrier, M: AMG, z, Dz0, c, maxit, lam_tol, log=None, schedule=None):
+    """One centering at fixed t (c already scaled by t): Newton on the subspaces R[J] for J in the level
+    schedule, each from s = 0, z += R[J] s.  its[l] = Newton steps on level l (docs/src/guide.md:158
+    `sum(SOL_main.its)`).  The literal coarse->fine loop ("all") de-centres the iterate at large t (coarse
+    directions drive single rows into the cone boundary) and costs ~8x more Newton steps than plain
+    path-following on the finest level, which is therefore the default."""
     L = len(M.R)
     its = np.zeros(L, dtype=np.int64)
     converged = True
-    for J in range(L):
+    if not hasattr(M, "BR"):
+        M.BR = {}
+    for J in level_schedule(L, schedule):
         R = M.R[J]
+        if J not in M.BR:
+            M.BR[J] = [sp.csr_matrix(Dk @ R) for Dk in M.D]
+        pre = (Dz0, M.BR[J])
         s0 = np.zeros(R.shape[1])
         crit = stopping_exact(0.1) if J == L - 1 else stopping_inexact(lam_tol, 0.5)
         lg = [] if log is not None else None
-        SOL = newton(lambda s: B.f0(s, M.x, M.w, c, R, M.D, z),
-                     lambda s: B.f1(s, M.x, M.w, c, R, M.D, z),
-                     lambda s: B.f2(s, M.x, M.w, c, R, M.D, z),
+        SOL = newton(lambda s, ref: B.f0_phi(s, M.x, M.w, c, R, M.D, z, ref, pre),
+                     lambda s: B.f1(s, M.x, M.w, c, R, M.D, z, pre),
+                     lambda s: B.f2(s, M.x, M.w, c, R, M.D, z, pre),
                      s0, maxit, crit, lg)
         its[J] = SOL["k"]
         if log is not None:
             log.append(dict(level=J, newton=lg))
         z = z + R @ SOL["x"]
+        Dz0 = B._Dz(SOL["x"], R, M.D, z, pre)          # the accepted Dz, carried forward
         if J == L - 1:
             converged = SOL["converged"]
-    return dict(z=z, its=its, converged=converged)
+    return dict(z=z, Dz0=Dz0, its=its, converged=converged)
 
 
-def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max_newton=None, log=None):
+def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max_newton=None, log=None,
+              schedule=None):
     if max_newton is None:
         max_newton = int(math.ceil(math.log2(-math.log2(np.finfo(np.float64).eps)))) + 2 + 40
     lam_tol = math.sqrt(float(np.min(M.w))) / 2
@@ -527,32 +581,32 @@ def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max
     kappa0 = kappa
     its, ts, cdots = [], [], []
 
-    def cdot(zz):
-        Dz = B.apply_D(M.D, zz)
+    def cdot(Dz):
         return float(sum(np.dot(M.w * c[:, k], Dz[:, k]) for k in range(len(M.D))))
 
-    SOL = amgb_step(B, M, z, t * c, max_newton, lam_tol, log)
+    Dz0 = B.apply_D(M.D, z)
+    SOL = amgb_step(B, M, z, Dz0, t * c, max_newton, lam_tol, log, schedule)
     if not SOL["converged"]:
         raise RuntimeError("amgb: initial centering failed at t=%g" % t)
-    z = SOL["z"]
-    its.append(SOL["its"]); ts.append(t); cdots.append(cdot(z))
+    z, Dz0 = SOL["z"], SOL["Dz0"]
+    its.append(SOL["its"]); ts.append(t); cdots.append(cdot(Dz0))
     k = 1
     while t <= 1 / tol and kappa > 1 and k < maxit:
         k += 1
         it_k = np.zeros(len(M.R), dtype=np.int64)
         while kappa > 1:
             t1 = kappa * t
-            SOL = amgb_step(B, M, z, t1 * c, max_newton, lam_tol, log)
+            SOL = amgb_step(B, M, z, Dz0, t1 * c, max_newton, lam_tol, log, schedule)
             it_k += SOL["its"]
             if SOL["converged"]:
                 if SOL["its"].max() <= max_newton * 0.5:
                     kappa = min(kappa0, kappa * kappa)
-                z, t = SOL["z"], t1
+                z, Dz0, t = SOL["z"], SOL["Dz0"], t1
                 break
             kappa = math.sqrt(kappa)
             if kappa < 1 + 1e-3:
                 kappa = 1.0
-        its.append(it_k); ts.append(t); cdots.append(cdot(z))
+        its.append(it_k); ts.append(t); cdots.append(cdot(Dz0))
     if t <= 1 / tol:
         raise RuntimeError("amgb: convergence failure at t=%g kappa=%g" % (t, kappa))
     return dict(z=z, its=np.array(its).T, ts=np.array(ts), c_dot_Dz=np.array(cdots),
@@ -570,7 +624,8 @@ class AMGBSOL:
 
 
 def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=None, g=None,
-         tol=None, t=0.1, maxit=10000, kappa=10.0, verbose=False, logfile=None, keep_log=False) -> AMGBSOL:
+         tol=None, t=0.1, maxit=10000, kappa=10.0, verbose=False, logfile=None, keep_log=False,
+         schedule=None) -> AMGBSOL:
     dim = geometry.discretization["dim"]
     f = DEFAULT_F[dim] if f is None else f
     g = DEFAULT_G[dim] if g is None else g
@@ -587,7 +642,7 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
     if not np.all(np.isfinite(Q.F(x, Dz))):
         raise NotImplementedError("oracle: feasibility phase not restated (SURVEY §8f-3); start must be strictly feasible")
     log = [] if keep_log else None
-    SOL = amgb_core(B, M, zvec, c, tol, t=t, maxit=maxit, kappa=kappa, log=log)
+    SOL = amgb_core(B, M, zvec, c, tol, t=t, maxit=maxit, kappa=kappa, log=log, schedule=schedule)
     z = SOL.pop("z").reshape(z0.shape, order="F")
     return AMGBSOL(z, None, SOL, log or [], geometry)
 

@@ -202,6 +202,32 @@ def test_infeasible_trial_is_reported_not_raised(M):
     assert np.isfinite(A.f0(l, np.zeros(N), 1.0))
 
 
+def test_fraction_to_boundary_trial_matches_oracle(M):
+    """Line-search trial semantics: finite only if every row keeps >= FRAC_TO_BOUNDARY of its cone distance."""
+    A, Mo, B, z0, c, go = _problem(M, "fem2d", 3, 1.0)
+    l = 2
+    Ro = Mo.R[l]
+    Rg = sp.block_diag([A.geometry.subspaces["dirichlet"][l].host, A.geometry.subspaces["full"][l].host], format="csr")
+    pi = _match_columns(Ro, Rg)
+    N = Ro.shape[1]
+    rng = np.random.default_rng(2)
+    d = rng.standard_normal(N)
+    t = 1.0
+    _, phi0 = B.f0_phi(np.zeros(N), Mo.x, Mo.w, t * c, Ro, Mo.D, z0)
+    seen = set()
+    for alpha in (1e-4, 1e-2, 0.3, 1.0, 3.0, 10.0, 30.0):
+        so = alpha * d
+        sg = np.zeros(N)
+        sg[pi] = so
+        yo, _ = B.f0_phi(so, Mo.x, Mo.w, t * c, Ro, Mo.D, z0, phi_ref=phi0)
+        yg = A.f0_trial(l, np.zeros(N), sg, t)
+        assert np.isfinite(yo) == np.isfinite(yg)
+        seen.add(bool(np.isfinite(yo)))
+        if np.isfinite(yo):
+            assert abs(yg - yo) <= KTOL * abs(yo)
+    assert seen == {True, False}                                  # the sweep crosses the rule
+
+
 # ---------------------------------------------------------------- whole solves
 CASES = [("fem1d", 3, 1.0), ("fem1d", 4, 2.0), ("fem2d", 2, 1.5), ("fem2d", 3, 1.0), ("fem2d", 3, 2.0)]
 
@@ -225,6 +251,21 @@ def test_solve_matches_oracle_and_golden(M, kind, L, p):
     # test/test_quick.jl:137-140 with 1e-7; we hold 1e-10)
     zo = getattr(O, kind + "_solve")(L=L, p=p).z
     assert rel(z, zo) < ZTOL
+
+
+@pytest.mark.parametrize("kind,L,p", [("fem1d", 4, 1.0), ("fem2d", 3, 1.5)])
+def test_level_loop_schedule_matches_oracle(M, kind, L, p):
+    """The literal coarse -> fine level loop (schedule='all', SURVEY §3.1 amgb_step) against the oracle run
+    with the same schedule; it must also land on the same z as the default schedule."""
+    sol = getattr(M, kind + "_mpi_solve")(L=L, p=p, schedule="all")
+    z = M.mpi_to_native(sol).z
+    so = getattr(O, kind + "_solve")(L=L, p=p, schedule="all")
+    assert rel(z, so.z) < ZTOL
+    its = sol.SOL_main["its"]
+    assert its.shape[0] == L and np.all(its.sum(axis=1) > 0)                  # every level visited
+    assert abs(int(its.sum()) - int(so.SOL_main["its"].sum())) <= max(3, 0.05 * so.SOL_main["its"].sum())
+    zf = M.mpi_to_native(getattr(M, kind + "_mpi_solve")(L=L, p=p)).z
+    assert rel(z, zf) < 1e-9
 
 
 @pytest.mark.parametrize("kind,L,p", [("fem2d", 5, 1.5), ("fem1d", 10, 1.0)])
