@@ -104,6 +104,11 @@ int mgb_amg_f1(mgb_amg a, int level, const double* s, double t, double* g);
 int mgb_amg_f2(mgb_amg a, int level, const double* s, double t, double* lower_vals);
 /* MultiGridBarrier.solve(A, b) = A \ b (test/test_instrumented_solve.jl:25-28,99), host direct solve */
 int mgb_amg_solve_linear(mgb_amg a, int level, const double* lower_vals, const double* g, double* x);
+/* the same solve with the device multifrontal Cholesky (csrc/gpuchol.hip): the solver the Newton loop uses
+ * by default.  Returns MGB_E_NUMERIC if a pivot is not positive. */
+int mgb_amg_solve_linear_gpu(mgb_amg a, int level, const double* lower_vals, const double* g, double* x);
+/* Newton linear solver: 0 (default) = GPU multifrontal Cholesky, 1 = host multifrontal Cholesky */
+int mgb_amg_set_solver(mgb_amg a, int host);
 /* amgb_step level schedule: 0 (default) = Newton on the finest subspace only, 1 = literal coarse -> fine
  * level loop (R_1 ... R_L).  Both end at the same z; see DESIGN.md section 2. */
 int mgb_amg_set_schedule(mgb_amg a, int all_levels);
@@ -130,6 +135,9 @@ int mgb_plan_pattern(mgb_plan p, int32_t* rowptr, int32_t* colidx);
 /* lower_vals = T * vec(Y) evaluated on the host: checks the plan against the reference's Hessian
  * recipe (test/test_matrix_addition.jl:39-95) in the CPU test-suite; not used by the product path */
 int mgb_plan_eval_host(mgb_plan p, const double* Y /* n x nY */, double* lower_vals);
+/* host-only timing of the multifrontal factorisation/solve of T*vec(Y) on this level's pattern */
+int mgb_plan_chol_bench(mgb_plan p, const double* Y, int dim, int reps, double* seconds_per_factor,
+                        double* seconds_per_solve, double* flops, double* front_doubles, double* residual);
 int mgb_chol_selftest(int nx, int ny, double* max_residual, double* flops, double* seconds);
 
 #ifdef __cplusplus

@@ -487,16 +487,23 @@ class AMG:
         Lo = sp.csr_matrix((vals, ci, rp), shape=(N, N))
         return Lo + sp.tril(Lo, -1).T, vals
 
-    def solve_linear(self, l, lower_vals, g):
+    def solve_linear(self, l, lower_vals, g, solver="gpu"):
+        """MultiGridBarrier.solve(A, b) = A \\ b on the level's fixed pattern: device (default) or host
+        multifrontal Cholesky."""
         lower_vals, g = f64(lower_vals), f64(g)
         x = np.empty_like(g)
-        call("mgb_amg_solve_linear", self.handle, l, dptr(lower_vals), dptr(g), dptr(x))
+        call("mgb_amg_solve_linear_gpu" if solver == "gpu" else "mgb_amg_solve_linear", self.handle, l,
+             dptr(lower_vals), dptr(g), dptr(x))
         return x
 
-    def solve(self, tol=None, t=0.1, kappa=10.0, maxit=10000, max_newton=0, verbose=0, schedule="fine"):
+    def solve(self, tol=None, t=0.1, kappa=10.0, maxit=10000, max_newton=0, verbose=0, schedule="fine",
+              solver="gpu"):
         if schedule not in ("fine", "all"):
             raise ValueError("schedule must be 'fine' or 'all'")
+        if solver not in ("gpu", "host"):
+            raise ValueError("solver must be 'gpu' or 'host'")
         call("mgb_amg_set_schedule", self.handle, 1 if schedule == "all" else 0)
+        call("mgb_amg_set_solver", self.handle, 1 if solver == "host" else 0)
         call("mgb_amg_solve", self.handle, float(tol or 0.0), float(t), float(kappa), int(maxit), int(max_newton),
              int(verbose))
         nt, te, tf = C.c_int(), C.c_double(), C.c_double()
@@ -547,7 +554,7 @@ class AMGBSOL:
 
 
 def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=None, g=None, tol=None, t=0.1,
-         maxit=10000, kappa=10.0, verbose=False, logfile=None, schedule="fine", **rest) -> AMGBSOL:
+         maxit=10000, kappa=10.0, verbose=False, logfile=None, schedule="fine", solver="gpu", **rest) -> AMGBSOL:
     """MultiGridBarrier.amgb on an MPI geometry (called at src:599,666).  kwargs as documented in
     docs/src/guide.md:148-152; unknown kwargs (e.g. `L`, forwarded by fem*d_mpi_solve, src:663-666)
     are ignored like Julia's `kwargs...` fan-out."""
@@ -567,7 +574,7 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
         raise NotImplementedError("amgb: the initial point is not strictly feasible; the feasibility phase "
                                   "(SOL_feasibility) is not built yet (SURVEY §8f-3)")
     SOL = M.solve(tol=tol, t=t, kappa=kappa, maxit=maxit, verbose=2 if verbose and verbose > 1 else int(bool(verbose)),
-                  schedule=schedule)
+                  schedule=schedule, solver=solver)
     z = M.get_z().reshape(z0.shape, order="F")
     return AMGBSOL(HPCMatrix(z, geometry.x.backend), None, SOL, [], geometry)
 

@@ -66,6 +66,8 @@ PROTOTYPES = {
     "mgb_amg_f1": [H, C.c_int, c_dbl_p, C.c_double, c_dbl_p],
     "mgb_amg_f2": [H, C.c_int, c_dbl_p, C.c_double, c_dbl_p],
     "mgb_amg_solve_linear": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],
+    "mgb_amg_solve_linear_gpu": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],
+    "mgb_amg_set_solver": [H, C.c_int],
     "mgb_amg_set_schedule": [H, C.c_int],
     "mgb_amg_solve": [H, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int],
     "mgb_amg_sol_info": [H, c_int_p, c_dbl_p, c_dbl_p, c_ll_p],
@@ -78,6 +80,7 @@ PROTOTYPES = {
     "mgb_plan_sizes": [H, c_int_p, c_int_p, c_int_p, c_int_p],
     "mgb_plan_pattern": [H, c_i32_p, c_i32_p],
     "mgb_plan_eval_host": [H, c_dbl_p, c_dbl_p],
+    "mgb_plan_chol_bench": [H, c_dbl_p, C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p],
     "mgb_chol_selftest": [C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],
 }
 _SPECIAL = {"mgb_last_error": ([], C.c_char_p), "mgb_version": ([], C.c_int), "mgb_device_count": ([], C.c_int)}

@@ -251,6 +251,8 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
   Y_.alloc((size_t)n_ * nY);
   phi_cur_.alloc(n_);
   phi_trial_.alloc(n_);
+  phi_trial2_.alloc(n_);
+  h_flag_.alloc(4);
   partials_.alloc((size_t)2 * f0_blocks(n_) + 16);
   scal_.alloc(8);
   h_scal_.alloc(8);
@@ -267,9 +269,12 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
     lv.BT.upload(lv.plan.BT);
     lv.T.upload(lv.plan.T);
     lv.chol.analyze(lv.plan.Apat, lv.plan.coords.data(), g.dim);
+    lv.gchol.build(lv.chol);
     const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
     lv.s.alloc(N);
     lv.s_trial.alloc(N);
+    lv.s_trial2.alloc(N);
+    lv.g_trial.alloc(N);
     lv.g.alloc(N);
     lv.nstep.alloc(N);
     lv.avals.alloc(nnzA);
@@ -353,12 +358,11 @@ void Amg::dev_apply(Level& lv, const double* s_dev) {
   timer_.end(ctx_.stream);
 }
 
-double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts, bool trial) {
+double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts, const double* phi_ref, double* phi_out) {
   dev_apply(lv, s_dev);
-  timer_.begin(ctx_.stream, KC_F0, (double)n_ * (2 * P_.K + 2 + (trial ? 1 : 0)) * 8);
-  // start of a Newton solve: record phi of the iterate; trial: test against it, keep the trial's phi aside
-  launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, trial ? phi_cur_.p : nullptr, kFracToBoundary,
-                    trial ? phi_trial_.p : phi_cur_.p, partials_.p, scal_.p);
+  timer_.begin(ctx_.stream, KC_F0, (double)n_ * (2 * P_.K + 2 + (phi_ref ? 1 : 0)) * 8);
+  // phi_ref == nullptr: start of a Newton solve (records phi of the iterate); otherwise a line-search trial
+  launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, phi_ref, kFracToBoundary, phi_out, partials_.p, scal_.p);
   timer_.end(ctx_.stream);
   hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
   sync_collect("sync f0");
@@ -369,20 +373,27 @@ double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts, bool
   return h_scal_.p[0] + t * h_scal_.p[1];
 }
 
-void Amg::dev_f1(Level& lv, const double* s_dev, double t, bool reuse_dz) {
+// gradient at s into g_out (device); returns |g|_2 (non-finite if any entry is)
+double Amg::dev_f1(Level& lv, const double* s_dev, double t, bool reuse_dz, double* g_out) {
   if (!reuse_dz) dev_apply(lv, s_dev);
   timer_.begin(ctx_.stream, KC_F1, (double)n_ * (3 * P_.K + 1) * 8);
   launch_barrier_f1(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, t, v_.p);
   timer_.end(ctx_.stream);
   timer_.begin(ctx_.stream, KC_RESTRICT, csr_bytes(lv.BT.view, false));
-  launch_spmv(ctx_.stream, lv.BT.view, v_.p, nullptr, lv.g.p);
+  launch_spmv(ctx_.stream, lv.BT.view, v_.p, nullptr, g_out);
   timer_.end(ctx_.stream);
-  hip_check(hipMemcpyAsync(lv.h_g.p, lv.g.p, (size_t)lv.plan.N * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
-            "D2H g");
+  launch_dot(ctx_.stream, lv.plan.N, g_out, g_out, partials_.p, scal_.p + 2);
+  hip_check(hipMemcpyAsync(h_scal_.p + 2, scal_.p + 2, sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H gg");
+  if (host_solve_)
+    hip_check(hipMemcpyAsync(lv.h_g.p, g_out, (size_t)lv.plan.N * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
+              "D2H g");
   sync_collect("sync f1");
+  return std::sqrt(h_scal_.p[2]);
 }
 
-bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st) {
+// Hessian at s, Newton direction nstep = H \ g (device); returns false if H is not numerically SPD.
+// inc = <g, nstep>.
+bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st, double* inc) {
   (void)t;
   const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
   dev_apply(lv, s_dev);
@@ -392,23 +403,53 @@ bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st)
   timer_.begin(ctx_.stream, KC_ASSEMBLE, csr_bytes(lv.T.view, false));
   launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
   timer_.end(ctx_.stream);
+  st.n_f2++;
+  st.n_factor++;
+  if (!host_solve_) {
+    // device multifrontal factorisation + sweeps: nothing but two scalars and a flag cross PCIe
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (live_) {
+      hip_check(hipEventCreate(&e0), "event");
+      hip_check(hipEventCreate(&e1), "event");
+      hip_check(hipEventRecord(e0, ctx_.stream), "record");
+    }
+    lv.gchol.factor(ctx_.stream, lv.avals.p);
+    lv.gchol.solve(ctx_.stream, lv.g.p, lv.nstep.p);
+    if (live_) hip_check(hipEventRecord(e1, ctx_.stream), "record");
+    launch_dot(ctx_.stream, N, lv.g.p, lv.nstep.p, partials_.p, scal_.p + 3);
+    hip_check(hipMemcpyAsync(h_scal_.p + 3, scal_.p + 3, sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H inc");
+    hip_check(hipMemcpyAsync(h_flag_.p, lv.gchol.fail_flag(), sizeof(int), hipMemcpyDeviceToHost, ctx_.stream), "D2H flag");
+    sync_collect("sync solve");
+    if (live_) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) st.time_factor += ms * 1e-3;
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
+    *inc = h_scal_.p[3];
+    return h_flag_.p[0] == 0;
+  }
   hip_check(hipMemcpyAsync(lv.h_avals.p, lv.avals.p, (size_t)nnzA * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
             "D2H avals");
   sync_collect("sync f2");
-  st.n_f2++;
   const double t0 = now_s();
   bool ok = lv.chol.factor(lv.h_avals.p);
+  double acc = 0;
   if (ok) {
     std::copy(lv.h_g.p, lv.h_g.p + N, lv.h_n.p);
     lv.chol.solve(lv.h_n.p);
+    for (int i = 0; i < N; ++i) acc += lv.h_g.p[i] * lv.h_n.p[i];
+    hip_check(hipMemcpyAsync(lv.nstep.p, lv.h_n.p, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx_.stream),
+              "H2D n");
   }
   st.time_factor += now_s() - t0;
-  st.n_factor++;
+  *inc = acc;
   return ok;
 }
 
 static const double kBeta = 0.5, kArmijo = 0.1, kMinStep = 1e-8;
-// kFracToBoundary (amg.hpp) = oracle FRAC_TO_BOUNDARY
+// kFracToBoundary (amg.hpp) = oracle FRAC_TO_BOUNDARY; the loop below mirrors oracle newton() +
+// linesearch_backtracking() (REFINE = True) statement by statement.
 
 Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int maxit, SolveStats& st, int verbose) {
   Level& lv = *levels_[l];
@@ -419,7 +460,7 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
     return res;
   }
   hip_check(hipMemsetAsync(lv.s.p, 0, (size_t)N * sizeof(double), ctx_.stream), "memset s");
-  double y = dev_f0(lv, lv.s.p, t, nullptr, false);
+  double y = dev_f0(lv, lv.s.p, t, nullptr, nullptr, phi_cur_.p);
   st.n_f0++;
   if (!std::isfinite(y)) {
     // diagnose: which rows left the cone
@@ -444,60 +485,68 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
              l, t, bad, n_, minphi, worst, y);
     throw std::runtime_error(buf);
   }
-  dev_f1(lv, lv.s.p, t, true);
+  double gnorm = dev_f1(lv, lv.s.p, t, true, lv.g.p);
   st.n_f1++;
-  auto norm2 = [&](const double* a) {
-    double s2 = 0;
-    for (int i = 0; i < N; ++i) s2 += a[i] * a[i];
-    return std::sqrt(s2);
-  };
-  double gnorm = norm2(lv.h_g.p);
   double ymin = y, gmin = gnorm, incmin = INFINITY;
   const double theta = finest ? 0.1 : 0.5;
+  double* sA = lv.s_trial.p;
+  double* sB = lv.s_trial2.p;
+  double* phiA = phi_trial_.p;
+  double* phiB = phi_trial2_.p;
   while (res.k < maxit && !res.converged) {
     res.k++;
-    if (!dev_f2_solve(lv, lv.s.p, t, st)) break;
     double inc = 0;
-    bool fin = true;
-    for (int i = 0; i < N; ++i) {
-      inc += lv.h_g.p[i] * lv.h_n.p[i];
-      fin = fin && std::isfinite(lv.h_n.p[i]);
-    }
-    if (!fin) break;
+    if (!dev_f2_solve(lv, lv.s.p, t, st, &inc)) break;
+    if (!std::isfinite(inc)) break;
     if (inc <= 0) {
       res.converged = true;
       break;
     }
-    hip_check(hipMemcpyAsync(lv.nstep.p, lv.h_n.p, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx_.stream),
-              "H2D n");
-    // backtracking line search: trial must be finite (amgb_all_isfinite, src:121) and satisfy Armijo
+    // backtracking line search: the trial must be finite (amgb_all_isfinite, src:121), respect the
+    // fraction-to-the-boundary rule and satisfy Armijo; then keep halving while the objective improves
     double step = 1.0, ynext = y, gnext = gnorm;
     bool accepted = false;
     while (step >= kMinStep) {
-      launch_waxpby(ctx_.stream, N, lv.s.p, -step, lv.nstep.p, lv.s_trial.p);
-      const double yt = dev_f0(lv, lv.s_trial.p, t, nullptr, true);
+      launch_waxpby(ctx_.stream, N, lv.s.p, -step, lv.nstep.p, sA);
+      double yA = dev_f0(lv, sA, t, nullptr, phi_cur_.p, phiA);
       st.n_f0++;
-      if (std::isfinite(yt) && yt <= y - kArmijo * step * inc) {
-        std::copy(lv.h_g.p, lv.h_g.p + N, lv.h_s.p);  // keep old gradient in case the new one is not finite
-        dev_f1(lv, lv.s_trial.p, t, true);
+      if (std::isfinite(yA) && yA <= y - kArmijo * step * inc) {
+        bool dz_is_A = true;
+        while (step * kBeta >= kMinStep) {
+          launch_waxpby(ctx_.stream, N, lv.s.p, -step * kBeta, lv.nstep.p, sB);
+          const double yB = dev_f0(lv, sB, t, nullptr, phi_cur_.p, phiB);
+          st.n_f0++;
+          if (!(std::isfinite(yB) && yB < yA)) {
+            dz_is_A = false;
+            break;
+          }
+          std::swap(sA, sB);
+          std::swap(phiA, phiB);
+          yA = yB;
+          step *= kBeta;
+          dz_is_A = true;
+        }
+        const double gn = dev_f1(lv, sA, t, dz_is_A, lv.g_trial.p);
         st.n_f1++;
-        bool gfin = true;
-        for (int i = 0; i < N; ++i) gfin = gfin && std::isfinite(lv.h_g.p[i]);
-        if (gfin) {
-          ynext = yt;
-          gnext = norm2(lv.h_g.p);
+        if (std::isfinite(gn)) {
+          ynext = yA;
+          gnext = gn;
           accepted = true;
           break;
         }
-        std::copy(lv.h_s.p, lv.h_s.p + N, lv.h_g.p);
       }
       step *= kBeta;
     }
     if (accepted) {
-      std::swap(lv.s.p, lv.s_trial.p);
-      std::swap(phi_cur_.p, phi_trial_.p);
+      std::swap(lv.s.p, sA);
+      std::swap(phi_cur_.p, phiA);
+      std::swap(lv.g.p, lv.g_trial.p);
+      if (host_solve_) std::swap(lv.h_g.p, lv.h_g.p);   // h_g already holds the accepted gradient
+    } else {
+      step = 0.0;
+      if (host_solve_)   // a rejected trial may have overwritten the host copy of the gradient
+        hip_check(hipMemcpy(lv.h_g.p, lv.g.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost), "D2H g");
     }
-    if (!accepted) step = 0.0;
     const bool exact = ynext >= ymin && gnext >= theta * gmin;
     if ((!finest && inc < lam_tol) || exact) res.converged = true;
     y = ynext;
@@ -508,6 +557,11 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
     if (verbose > 1)
       fprintf(stderr, "    [mgb] level %d k=%d y=%.12g |g|=%.3g inc=%.3g step=%.3g\n", l, res.k, y, gnorm, inc, step);
   }
+  // hand the scratch buffers back (pointer identities may have rotated)
+  lv.s_trial.p = sA;
+  lv.s_trial2.p = sB;
+  phi_trial_.p = phiA;
+  phi_trial2_.p = phiB;
   return res;
 }
 
@@ -559,6 +613,7 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   const double kappa0 = opt.kappa;
   const size_t zbytes = (size_t)n_ * S_ * sizeof(double), dzbytes = (size_t)n_ * P_.K * sizeof(double);
   schedule_all_ = opt.schedule_all;
+  host_solve_ = opt.host_solve;
   std::vector<long long> its(L, 0);
   refresh_dz0();
   if (!amgb_step(t, lam_tol, opt.max_newton, its, st, opt.verbose))
@@ -607,22 +662,22 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
 double Amg::f0(int l, const double* s_host, double t, double* parts) {
   Level& lv = *levels_.at(l);
   lv.s_trial.upload(s_host, lv.plan.N);
-  return dev_f0(lv, lv.s_trial.p, t, parts, false);
+  return dev_f0(lv, lv.s_trial.p, t, parts, nullptr, phi_cur_.p);
 }
 
 double Amg::f0_trial(int l, const double* s_ref_host, const double* s_host, double t) {
   Level& lv = *levels_.at(l);
   lv.s_trial.upload(s_ref_host, lv.plan.N);
-  dev_f0(lv, lv.s_trial.p, t, nullptr, false);     // records phi of the reference iterate
+  dev_f0(lv, lv.s_trial.p, t, nullptr, nullptr, phi_cur_.p);     // records phi of the reference iterate
   lv.s_trial.upload(s_host, lv.plan.N);
-  return dev_f0(lv, lv.s_trial.p, t, nullptr, true);
+  return dev_f0(lv, lv.s_trial.p, t, nullptr, phi_cur_.p, phi_trial_.p);
 }
 
 void Amg::f1(int l, const double* s_host, double t, double* g_host) {
   Level& lv = *levels_.at(l);
   lv.s_trial.upload(s_host, lv.plan.N);
-  dev_f1(lv, lv.s_trial.p, t, false);
-  std::copy(lv.h_g.p, lv.h_g.p + lv.plan.N, g_host);
+  dev_f1(lv, lv.s_trial.p, t, false, lv.g_trial.p);
+  lv.g_trial.download(g_host, lv.plan.N);
 }
 
 void Amg::f2(int l, const double* s_host, double t, double* avals_host) {
@@ -642,6 +697,19 @@ void Amg::apply_D(int l, const double* s_host, double* Dz_host) {
   dev_apply(lv, lv.s_trial.p);
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   Dz_.download(Dz_host, (size_t)n_ * P_.K);
+}
+
+bool Amg::solve_device(int l, const double* avals, const double* g, double* nstep) {
+  Level& lv = *levels_.at(l);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync");
+  lv.avals.upload(avals, lv.plan.Apat.nnz());
+  lv.g_trial.upload(g, lv.plan.N);
+  lv.gchol.factor(ctx_.stream, lv.avals.p);
+  lv.gchol.solve(ctx_.stream, lv.g_trial.p, lv.nstep.p);
+  hip_check(hipMemcpyAsync(h_flag_.p, lv.gchol.fail_flag(), sizeof(int), hipMemcpyDeviceToHost, ctx_.stream), "D2H flag");
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync");
+  lv.nstep.download(nstep, lv.plan.N);
+  return h_flag_.p[0] == 0;
 }
 
 bool Amg::solve_host(int l, const double* avals, const double* g, double* nstep) {

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "geometry.hpp"
+#include "gpuchol.hpp"
 #include "kernels.hpp"
 #include "mfchol.hpp"
 
@@ -109,6 +110,7 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
 constexpr double kFracToBoundary = 0.1;   // == oracle FRAC_TO_BOUNDARY
 
 struct SolveOptions {
+  bool host_solve = false;              // true: factor/solve on the host (MfChol), false: on the GPU (GpuChol)
   bool schedule_all = false;            // false: finest level only; true: coarse -> fine level loop
   bool time_kernels = true;             // bracket kernels with HIP events (a few us of host time per step)
   double tol = 1.4901161193847656e-08;  // sqrt(eps)
@@ -180,6 +182,8 @@ class Amg {
   void apply_D(int l, const double* s_host, double* Dz_host);          // n x K row-major
   // solve (R'HR) nstep = g with the level's multifrontal factorization; returns false if not SPD
   bool solve_host(int l, const double* avals, const double* g, double* nstep);
+  // the same on the device (GpuChol): host arrays in/out, for parity tests of the device solver
+  bool solve_device(int l, const double* avals, const double* g, double* nstep);
 
   // full multigrid-barrier solve from the current z; z updated in place
   void solve(const SolveOptions& opt, SolveStats& st);
@@ -195,8 +199,9 @@ class Amg {
   struct Level {
     LevelPlan plan;
     DevCsrOwned R, B, BT, T;
-    MfChol chol;
-    DevBuf<double> s, s_trial, g, nstep, avals;
+    MfChol chol;      // symbolic structure (+ host numeric path)
+    GpuChol gchol;    // device numeric factorisation / sweeps on the same tree
+    DevBuf<double> s, s_trial, s_trial2, g, g_trial, nstep, avals;
     PinnedBuf<double> h_avals, h_g, h_n, h_s;
   };
   struct NewtonResult {
@@ -205,9 +210,9 @@ class Amg {
   };
   void refresh_dz0();
   void dev_apply(Level& lv, const double* s_dev);                 // Dz = Dz0 + B s
-  double dev_f0(Level& lv, const double* s_dev, double t, double* parts, bool trial);
-  void dev_f1(Level& lv, const double* s_dev, double t, bool reuse_dz);   // -> lv.g and lv.h_g
-  bool dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st);  // -> lv.h_n / lv.nstep
+  double dev_f0(Level& lv, const double* s_dev, double t, double* parts, const double* phi_ref, double* phi_out);
+  double dev_f1(Level& lv, const double* s_dev, double t, bool reuse_dz, double* g_out);   // returns |g|
+  bool dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st, double* inc);  // -> lv.nstep
   NewtonResult newton(int l, double t, bool finest, double lam_tol, int maxit, SolveStats& st, int verbose);
   bool amgb_step(double t, double lam_tol, int max_newton, std::vector<long long>& its, SolveStats& st, int verbose);
   double c_dot_dz();
@@ -218,7 +223,9 @@ class Amg {
   AmgSpec spec_;
   DevCsrOwned Dstack_;
   std::vector<std::unique_ptr<Level>> levels_;
-  DevBuf<double> w_, c_, z_, z_save_, Dz0_, Dz0_save_, Dz_, v_, Y_, partials_, scal_, phi_cur_, phi_trial_;
+  DevBuf<double> w_, c_, z_, z_save_, Dz0_, Dz0_save_, Dz_, v_, Y_, partials_, scal_, phi_cur_, phi_trial_, phi_trial2_;
+  PinnedBuf<int> h_flag_;
+  bool host_solve_ = false;
   PinnedBuf<double> h_scal_;
   double w_min_ = 0;
   bool schedule_all_ = false;

@@ -12,8 +12,9 @@ for f in geometry mfchol; do
   fi
 done
 "$HIPCC" --offload-arch=gfx950 $CXXFLAGS -c "$HERE/kernels.hip" -o "$HERE/_obj/kernels.o" &
+"$HIPCC" --offload-arch=gfx950 $CXXFLAGS -c "$HERE/gpuchol.hip" -o "$HERE/_obj/gpuchol.o" &
 "$HIPCC" --offload-arch=gfx950 $CXXFLAGS -x hip -c "$HERE/amg.cpp" -o "$HERE/_obj/amg.o" &
 "$HIPCC" --offload-arch=gfx950 $CXXFLAGS -x hip -c "$HERE/capi.cpp" -o "$HERE/_obj/capi.o" &
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libmgb_hip.so" "$HERE"/_obj/{geometry,mfchol,kernels,amg,capi}.o -lpthread
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libmgb_hip.so" "$HERE"/_obj/{geometry,mfchol,kernels,gpuchol,amg,capi}.o -lpthread
 echo "built $OUT/libmgb_hip.so"

@@ -31,6 +31,7 @@ struct mgb_amg_s {
   std::unique_ptr<Amg> amg;
   SolveStats stats;
   bool schedule_all = false;
+  bool host_solve = false;
 };
 struct mgb_plan_s {
   LevelPlan plan;
@@ -509,6 +510,18 @@ int mgb_amg_solve_linear(mgb_amg a, int level, const double* lower_vals, const d
     if (!a->amg->solve_host(level, lower_vals, g, x)) throw std::runtime_error("MfChol: matrix is not positive definite");
   });
 }
+int mgb_amg_solve_linear_gpu(mgb_amg a, int level, const double* lower_vals, const double* g, double* x) {
+  return guard([&] {
+    need(a && lower_vals && g && x && level >= 0 && level < a->amg->L(), "solve_linear_gpu: bad arguments");
+    if (!a->amg->solve_device(level, lower_vals, g, x)) throw std::runtime_error("MfChol: matrix is not positive definite");
+  });
+}
+int mgb_amg_set_solver(mgb_amg a, int host) {
+  return guard([&] {
+    need(a, "null amg");
+    a->host_solve = host != 0;
+  });
+}
 int mgb_amg_set_schedule(mgb_amg a, int all_levels) {
   return guard([&] {
     need(a, "null amg");
@@ -520,6 +533,7 @@ int mgb_amg_solve(mgb_amg a, double tol, double t0, double kappa, int maxit, int
     need(a, "null amg");
     SolveOptions o;
     o.schedule_all = a->schedule_all;
+    o.host_solve = a->host_solve;
     if (tol > 0) o.tol = tol;
     if (t0 > 0) o.t0 = t0;
     if (kappa > 1) o.kappa = kappa;
@@ -617,6 +631,48 @@ int mgb_plan_eval_host(mgb_plan p, const double* Y, double* lower_vals) {
   return guard([&] {
     need(p && Y && lower_vals, "null argument");
     spmv_host(p->plan.T, Y, lower_vals);
+  });
+}
+
+int mgb_plan_chol_bench(mgb_plan p, const double* Y, int dim, int reps, double* seconds_per_factor,
+                        double* seconds_per_solve, double* flops, double* front_doubles, double* residual) {
+  return guard([&] {
+    need(p && Y && reps > 0, "chol_bench: bad arguments");
+    const LevelPlan& pl = p->plan;
+    std::vector<double> vals(pl.Apat.nnz());
+    spmv_host(pl.T, Y, vals.data());
+    MfChol ch;
+    ch.analyze(pl.Apat, pl.coords.data(), dim);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r)
+      if (!ch.factor(vals.data())) throw std::runtime_error("MfChol: bench matrix not SPD");
+    const double tf = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+    const int N = pl.N;
+    std::vector<double> xs(N), b(N, 0.0);
+    for (int i = 0; i < N; ++i) xs[i] = std::sin(0.37 * i) + 0.1;
+    for (int r = 0; r < N; ++r)
+      for (int k = pl.Apat.rowptr[r]; k < pl.Apat.rowptr[r + 1]; ++k) {
+        const int c = pl.Apat.colidx[k];
+        b[r] += vals[k] * xs[c];
+        if (c != r) b[c] += vals[k] * xs[r];
+      }
+    std::vector<double> b0 = b;
+    t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) {
+      b = b0;
+      ch.solve(b.data());
+    }
+    const double ts = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+    double mx = 0, sc = 0;
+    for (int i = 0; i < N; ++i) {
+      mx = std::max(mx, std::fabs(b[i] - xs[i]));
+      sc = std::max(sc, std::fabs(xs[i]));
+    }
+    if (seconds_per_factor) *seconds_per_factor = tf;
+    if (seconds_per_solve) *seconds_per_solve = ts;
+    if (flops) *flops = ch.factor_flops();
+    if (front_doubles) *front_doubles = (double)ch.front_doubles();
+    if (residual) *residual = mx / sc;
   });
 }
 

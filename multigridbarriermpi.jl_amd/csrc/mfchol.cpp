@@ -1,7 +1,12 @@
 #include "mfchol.hpp"
 
+#include <sched.h>
+
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 namespace mgb {
@@ -11,7 +16,17 @@ namespace {
 int hw_threads() {
   static int n = [] {
     const char* e = getenv("MGB_NUM_THREADS");
-    int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    int v = 0;
+    if (e) {
+      v = atoi(e);
+    } else {
+      // cores this process may actually run on (cgroup / affinity), not the machine's core count
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      if (sched_getaffinity(0, sizeof(set), &set) == 0) v = CPU_COUNT(&set);
+      if (v <= 0) v = (int)std::thread::hardware_concurrency();
+      if (v > 16) v = 16;   // the factorisation stops scaling beyond that; leave room for sibling ranks
+    }
     if (v < 1) v = 1;
     if (v > 64) v = 64;
     return v;
@@ -19,25 +34,96 @@ int hw_threads() {
   return n;
 }
 
+// Persistent worker pool: parallel_for hands out indices through an atomic counter; workers sleep on a
+// condition variable between calls (thread creation per call cost more than the small fronts).
+class Pool {
+ public:
+  static Pool& get() {
+    static Pool p(hw_threads());
+    return p;
+  }
+  int size() const { return (int)workers_.size() + 1; }
+  template <class F>
+  void run(int n, F&& fn) {
+    if (n <= 0) return;
+    if (workers_.empty() || n == 1 || busy_.exchange(true)) {   // nested / concurrent use: run inline
+      for (int i = 0; i < n; ++i) fn(i);
+      return;
+    }
+    std::function<void(int)> f = fn;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &f;
+      n_ = n;
+      next_.store(0);
+      pending_ = (int)workers_.size();
+      ++epoch_;
+    }
+    cv_.notify_all();
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= n) break;
+      f(i);
+    }
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+    busy_.store(false);
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+      ++epoch_;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+
+ private:
+  explicit Pool(int nthreads) {
+    for (int t = 1; t < nthreads; ++t) workers_.emplace_back([this] { loop(); });
+  }
+  void loop() {
+    unsigned long seen = 0;
+    for (;;) {
+      std::function<void(int)>* f;
+      int n;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return epoch_ != seen; });
+        seen = epoch_;
+        if (stop_) return;
+        f = fn_;
+        n = n_;
+      }
+      for (;;) {
+        const int i = next_.fetch_add(1);
+        if (i >= n) break;
+        (*f)(i);
+      }
+      std::lock_guard<std::mutex> lk(m_);
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  std::function<void(int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  std::atomic<bool> busy_{false};
+  int n_ = 0, pending_ = 0;
+  unsigned long epoch_ = 0;
+  bool stop_ = false;
+};
+
 template <class F>
 void parallel_for(int n, int nthreads, F&& fn) {
   if (nthreads <= 1 || n <= 1) {
     for (int i = 0; i < n; ++i) fn(i);
     return;
   }
-  std::atomic<int> next(0);
-  auto work = [&] {
-    for (;;) {
-      int i = next.fetch_add(1);
-      if (i >= n) break;
-      fn(i);
-    }
-  };
-  std::vector<std::thread> th;
-  int nt = std::min(nthreads, n);
-  for (int t = 1; t < nt; ++t) th.emplace_back(work);
-  work();
-  for (auto& t : th) t.join();
+  Pool::get().run(n, fn);
 }
 
 // C(m x m, lower, ld) -= P(m x kw, ld) * P^T for columns [j0, j1) ; C and P column-major.

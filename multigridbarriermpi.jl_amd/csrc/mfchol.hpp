@@ -32,6 +32,7 @@ class MfChol {
   int max_front() const { return max_front_; }
 
  private:
+  friend class GpuChol;   // the device factorisation reuses this symbolic structure verbatim
   struct Node {
     int parent = -1;
     int first = 0, ns = 0;      // own dofs: new indices [first, first+ns)

