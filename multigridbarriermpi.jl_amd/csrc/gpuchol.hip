@@ -29,85 +29,123 @@ __global__ __launch_bounds__(TB) void scatter_kernel(int n, const int* __restric
     fronts[dst[k]] = vals[src[k]];
 }
 
-// parent front += child's Schur complement (one workgroup per child; the two child slots of a height are
-// separate launches, so two siblings never add into the same entry concurrently)
-__global__ __launch_bounds__(TB) void extend_add_kernel(const GNode* __restrict__ nodes, const int* __restrict__ list,
+// broadcast lane `lane` (compile-time constant) of a double through SGPRs
+__device__ inline double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// parent front += child's Schur complement.  One workgroup per (child, chunk of 8 boundary columns); the two
+// child slots of a height are separate launches, so siblings never add into the same entry concurrently.
+constexpr int EA_COLS = 8;
+__global__ __launch_bounds__(TB) void extend_add_kernel(const GNode* __restrict__ nodes, const GTile* __restrict__ list,
                                                          const int* __restrict__ ea_all, double* fronts) {
-  const GNode c = nodes[list[blockIdx.x]];
+  const GTile job = list[blockIdx.x];
+  const GNode c = nodes[job.node];
   const GNode p = nodes[c.parent];
   const int nb = c.nf - c.ns;
   const int* ea = ea_all + c.bofs;
   const double* Fc = fronts + c.off;
   double* Fp = fronts + p.off;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int b = wave; b < nb; b += TB / 64) {
+  const int b0 = job.ti * EA_COLS, b1 = min(nb, b0 + EA_COLS);
+  for (int b = b0 + wave; b < b1; b += TB / 64) {
     const long long pc = (long long)p.nf * ea[b];
     const double* col = Fc + (long long)c.nf * (c.ns + b) + c.ns;
     for (int a = b + lane; a < nb; a += 64) Fp[pc + ea[a]] += col[a];
   }
 }
 
-// Panel p of every listed front: Cholesky of the 32x32 diagonal block (in LDS), its inverse (kept in the
-// strictly upper triangle of the block), and L21 = F21 * L11^{-T} for all rows below.
-__global__ __launch_bounds__(TB) void panel_factor_kernel(const GNode* __restrict__ nodes, const int* __restrict__ list,
-                                                           int p, double* fronts, int* fail) {
+// Panel p of every listed front, rows [k1 + 256*slice, ...): every workgroup re-derives the Cholesky factor
+// of the ORIGINAL 32x32 diagonal block (wave-level, rows in registers, cross-lane shuffles) and its inverse,
+// so the slices of one front run concurrently without reading anything another slice writes; slice 0 stores
+// the inverse (both orientations) to the scratch the sweeps read.  L21 = F21 * L11^{-T}.
+constexpr int SLICE = TB;
+__global__ __launch_bounds__(TB) void panel_factor_kernel(const GNode* __restrict__ nodes, const GTile* __restrict__ list,
+                                                           int p, double* fronts, double* linv, int* fail) {
   __shared__ double Ls[PB][PB + 1];
   __shared__ double Is[PB][PB + 1];
-  const GNode nd = nodes[list[blockIdx.x]];
+  const GTile job = list[blockIdx.x];
+  const GNode nd = nodes[job.node];
   const int nf = nd.nf, k0 = p * PB, kw = min(PB, nd.ns - k0), k1 = k0 + kw;
   double* F = fronts + nd.off;
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < PB * PB; idx += TB) {
-    const int i = idx % PB, j = idx / PB;
-    double v = (i == j) ? 1.0 : 0.0;
-    if (i < kw && j < kw && i >= j) v = F[(long long)nf * (k0 + j) + k0 + i];
-    Ls[i][j] = v;
-    Is[i][j] = 0.0;
-  }
-  __syncthreads();
-  for (int k = 0; k < kw; ++k) {
-    if (tid == 0) {
-      double d = Ls[k][k];
-      if (!(d > 0.0) || !isfinite(d)) {
-        atomicOr(fail, 1);
-        d = 1.0;
+  if (tid < 64) {
+    // lane i (< 32) owns row i of the block (padded with the identity beyond kw).  Column k of L is
+    // broadcast with constant-lane v_readlane (no LDS round trip); entries right of the diagonal of a row
+    // are don't-care (their multiplier l is forced to 0 once k passes the row), so the update is branch-free.
+    const int i = tid & 31;
+    double a[PB], rdv[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      double v = (i == j) ? 1.0 : 0.0;
+      if (i < kw && j < kw && j <= i) v = F[(long long)nf * (k0 + j) + k0 + i];
+      a[j] = v;
+    }
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+      double akk = readlane_f64(a[k], k);
+      if (!(akk > 0.0) || !isfinite(akk)) {
+        bad = true;
+        akk = 1.0;
       }
-      Ls[k][k] = sqrt(d);
+      const double rd = rsqrt(akk);          // 1 / L[k][k]
+      rdv[k] = rd;
+      const double l = (i > k) ? a[k] * rd : ((i == k) ? akk * rd : 0.0);
+      a[k] = l;
+#pragma unroll
+      for (int j = k + 1; j < PB; ++j) a[j] = fma(-l, readlane_f64(l, j), a[j]);
     }
-    __syncthreads();
-    if (tid > k && tid < kw) Ls[tid][k] /= Ls[k][k];
-    __syncthreads();
-    for (int idx = tid; idx < kw * kw; idx += TB) {
-      const int i = idx % kw, j = idx / kw;
-      if (j > k && i >= j) Ls[i][j] -= Ls[i][k] * Ls[j][k];
+    if (bad && tid == 0) atomicOr(fail, 1);
+    if (tid < PB) {
+#pragma unroll
+      for (int j = 0; j < PB; ++j) Ls[i][j] = (j <= i) ? a[j] : 0.0;
+      // column c = i of L^{-1} by forward substitution; L entries are LDS broadcasts of OTHER rows, so
+      // make the block visible to the wave first
     }
-    __syncthreads();
-  }
-  // inverse of the lower-triangular block: column c by forward substitution (one thread per column)
-  if (tid < kw) {
-    const int c = tid;
-    Is[c][c] = 1.0 / Ls[c][c];
-    for (int i = c + 1; i < kw; ++i) {
-      double s = 0.0;
-      for (int m = c; m < i; ++m) s += Ls[i][m] * Is[m][c];
-      Is[i][c] = -s / Ls[i][i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (tid < PB) {
+      const int c = i;
+      double x[PB];
+#pragma unroll
+      for (int r = 0; r < PB; ++r) {
+        double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+        for (int m = 0; m + 1 < r; m += 2) {
+          s0 = fma(-Ls[r][m], x[m], s0);
+          s1 = fma(-Ls[r][m + 1], x[m + 1], s1);
+        }
+        if (r & 1) s0 = fma(-Ls[r][r - 1], x[r - 1], s0);
+        x[r] = (s0 + s1) * rdv[r];
+      }
+#pragma unroll
+      for (int r = 0; r < PB; ++r) Is[r][c] = (r >= c) ? x[r] : 0.0;
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < kw * kw; idx += TB) {
-    const int i = idx % kw, j = idx / kw;
-    if (i >= j) F[(long long)nf * (k0 + j) + k0 + i] = Ls[i][j];          // L11
-    else F[(long long)nf * (k0 + j) + k0 + i] = Is[j][i];                 // (L11^{-1})' strictly upper
+  if (job.ti == 0) {
+    double* lp = linv + nd.loff + (long long)p * 2 * PB * PB;
+    for (int idx = tid; idx < PB * PB; idx += TB) {
+      const int i = idx % PB, j = idx / PB;
+      lp[idx] = Is[i][j];                 // Linv, column-major: lp[i + 32 j] = Linv[i][j]
+      lp[PB * PB + idx] = Is[j][i];       // its transpose, column-major
+    }
   }
-  // rows below the block: x = f * L11^{-T}, i.e. x_j = sum_{m<=j} f_m Linv[j][m]
-  for (int i = k1 + tid; i < nf; i += TB) {
+  // rows of this slice: x = f * L11^{-T}, i.e. x_j = sum_{m<=j} f_m Linv[j][m]
+  const int i = k1 + job.ti * SLICE + tid;
+  if (i < nf) {
     double f[PB];
 #pragma unroll
     for (int j = 0; j < PB; ++j) f[j] = (j < kw) ? F[(long long)nf * (k0 + j) + i] : 0.0;
 #pragma unroll
-    for (int j = PB - 1; j >= 0; --j) {
+    for (int j = 0; j < PB; ++j) {
       if (j < kw) {
         double s = 0.0;
+#pragma unroll
         for (int m = 0; m <= j; ++m) s += f[m] * Is[j][m];
         F[(long long)nf * (k0 + j) + i] = s;
       }
@@ -160,24 +198,26 @@ __global__ __launch_bounds__(TB) void scatter_perm_kernel(int n, const int* __re
 }
 
 // Forward sweep L u = b of one height: front-local vector u = [own | bdry] in LDS; children's boundary
-// parts are pulled in slot order, own part solved panel by panel with the stored block inverses.
-__global__ __launch_bounds__(TB) void forward_kernel(const GNode* __restrict__ nodes, const int* __restrict__ list,
+// parts are pulled in slot order, the own part is solved panel by panel with the stored block inverses,
+// then the boundary part is updated in one pass (u_bdry -= L21 u_own).
+template <int NT>
+__global__ __launch_bounds__(NT) void forward_kernel(const GNode* __restrict__ nodes, const int* __restrict__ list,
                                                       const int* __restrict__ ea_all, const double* __restrict__ fronts,
-                                                      double* y, double* work) {
+                                                      const double* __restrict__ linv, double* y, double* work) {
   extern __shared__ double u[];
   __shared__ double tmp[PB];
   const GNode nd = nodes[list[blockIdx.x]];
-  const int nf = nd.nf, ns = nd.ns, tid = threadIdx.x;
+  const int nf = nd.nf, ns = nd.ns, nb = nf - ns, tid = threadIdx.x;
   const double* F = fronts + nd.off;
-  for (int i = tid; i < nf; i += TB) u[i] = (i < ns) ? y[nd.first + i] : 0.0;
+  for (int i = tid; i < nf; i += NT) u[i] = (i < ns) ? y[nd.first + i] : 0.0;
   __syncthreads();
   for (int s = 0; s < 2; ++s) {
     if (nd.child[s] >= 0) {
       const GNode c = nodes[nd.child[s]];
-      const int nb = c.nf - c.ns;
+      const int cnb = c.nf - c.ns;
       const int* ea = ea_all + c.bofs;
       const double* wc = work + c.woff + c.ns;
-      for (int i = tid; i < nb; i += TB) u[ea[i]] += wc[i];
+      for (int i = tid; i < cnb; i += NT) u[ea[i]] += wc[i];
     }
     __syncthreads();
   }
@@ -185,29 +225,42 @@ __global__ __launch_bounds__(TB) void forward_kernel(const GNode* __restrict__ n
     const int kw = min(PB, ns - k0), k1 = k0 + kw;
     if (tid < kw) {
       const int j = tid;
-      double s = u[k0 + j] / F[(long long)nf * (k0 + j) + k0 + j];           // Linv[j][j] = 1/L[j][j]
-      for (int m = 0; m < j; ++m) s += F[(long long)nf * (k0 + j) + k0 + m] * u[k0 + m];   // Linv[j][m] at (row m, col j)
+      const double* lp = linv + nd.loff + (long long)(k0 / PB) * 2 * PB * PB;    // Linv[j][m] at lp[j + 32 m]
+      double s = 0.0;
+      for (int m = 0; m <= j; ++m) s += lp[j + PB * m] * u[k0 + m];
       tmp[j] = s;
     }
     __syncthreads();
     if (tid < kw) u[k0 + tid] = tmp[tid];
     __syncthreads();
-    for (int i = k1 + tid; i < nf; i += TB) {
+    for (int i = k1 + tid; i < ns; i += NT) {
       double d = 0.0;
       for (int j = 0; j < kw; ++j) d += F[(long long)nf * (k0 + j) + i] * u[k0 + j];
       u[i] -= d;
     }
     __syncthreads();
   }
-  for (int i = tid; i < ns; i += TB) y[nd.first + i] = u[i];
-  double* w = work + nd.woff;
-  for (int i = ns + tid; i < nf; i += TB) w[i] = u[i];
+  for (int i = tid; i < ns; i += NT) y[nd.first + i] = u[i];
+  double* w = work + nd.woff + ns;
+  for (int i = tid; i < nb; i += NT) {
+    const double* row = F + ns + i;
+    double d0 = 0.0, d1 = 0.0;
+    int j = 0;
+    for (; j + 1 < ns; j += 2) {
+      d0 += row[(long long)nf * j] * u[j];
+      d1 += row[(long long)nf * (j + 1)] * u[j + 1];
+    }
+    if (j < ns) d0 += row[(long long)nf * j] * u[j];
+    w[i] = u[ns + i] - (d0 + d1);
+  }
 }
 
 // Backward sweep L' x = u of one height (heights descending): ancestors' entries of x are final.
-__global__ __launch_bounds__(TB) void backward_kernel(const GNode* __restrict__ nodes, const int* __restrict__ list,
+template <int NT>
+__global__ __launch_bounds__(NT) void backward_kernel(const GNode* __restrict__ nodes, const int* __restrict__ list,
                                                        const int* __restrict__ bdry_all,
-                                                       const double* __restrict__ fronts, double* y) {
+                                                       const double* __restrict__ fronts,
+                                                       const double* __restrict__ linv, double* y) {
   extern __shared__ double u[];      // [0,ns): rhs -> solution ; [ns,nf): x of the boundary dofs
   __shared__ double tmp[PB];
   const GNode nd = nodes[list[blockIdx.x]];
@@ -215,10 +268,10 @@ __global__ __launch_bounds__(TB) void backward_kernel(const GNode* __restrict__ 
   const int lane = tid & 63, wave = tid >> 6;
   const double* F = fronts + nd.off;
   const int* bd = bdry_all + nd.bofs;
-  for (int i = tid; i < nf; i += TB) u[i] = (i < ns) ? y[nd.first + i] : y[bd[i - ns]];
+  for (int i = tid; i < nf; i += NT) u[i] = (i < ns) ? y[nd.first + i] : y[bd[i - ns]];
   __syncthreads();
   // u_own -= L21' x_bdry : column j of L21 is contiguous
-  for (int j = wave; j < ns; j += TB / 64) {
+  for (int j = wave; j < ns; j += NT / 64) {
     const double* col = F + (long long)nf * j + ns;
     double s = 0.0;
     for (int i = lane; i < nb; i += 64) s += col[i] * u[ns + i];
@@ -231,7 +284,7 @@ __global__ __launch_bounds__(TB) void backward_kernel(const GNode* __restrict__ 
   for (int pp = npanel - 1; pp >= 0; --pp) {
     const int k0 = pp * PB, kw = min(PB, ns - k0), k1 = k0 + kw;
     // u_p -= L[k1:ns, panel]' x[k1:ns]
-    for (int c = wave; c < kw; c += TB / 64) {
+    for (int c = wave; c < kw; c += NT / 64) {
       const double* col = F + (long long)nf * (k0 + c);
       double s = 0.0;
       for (int i = k1 + lane; i < ns; i += 64) s += col[i] * u[i];
@@ -241,16 +294,17 @@ __global__ __launch_bounds__(TB) void backward_kernel(const GNode* __restrict__ 
     }
     __syncthreads();
     if (tid < kw) {
-      const int c = tid;     // x_c = sum_{m>=c} Linv[m][c] u_m ; Linv[m][c] (m>c) sits at (row c, col m)
-      double s = u[k0 + c] / F[(long long)nf * (k0 + c) + k0 + c];
-      for (int m = c + 1; m < kw; ++m) s += F[(long long)nf * (k0 + m) + k0 + c] * u[k0 + m];
+      const int c = tid;     // x_c = sum_{m>=c} Linv[m][c] u_m ; transpose block: lt[c + 32 m] = Linv[m][c]
+      const double* lt = linv + nd.loff + (long long)pp * 2 * PB * PB + PB * PB;
+      double s = 0.0;
+      for (int m = c; m < kw; ++m) s += lt[c + PB * m] * u[k0 + m];
       tmp[c] = s;
     }
     __syncthreads();
     if (tid < kw) u[k0 + tid] = tmp[tid];
     __syncthreads();
   }
-  for (int i = tid; i < ns; i += TB) y[nd.first + i] = u[i];
+  for (int i = tid; i < ns; i += NT) y[nd.first + i] = u[i];
 }
 
 inline int blocks_for(long long n) {
@@ -280,13 +334,15 @@ void GpuChol::build(const MfChol& sym) {
   flops_ = sym.flops_;
   std::vector<GNode> nodes(nnodes_);
   std::vector<int> bdry_all, ea_all, height(nnodes_, 0);
-  long long off = 0, woff = 0;
+  long long off = 0, woff = 0, loff = 0;
   max_nf_ = 0;
   for (int t = 0; t < nnodes_; ++t) {
     const auto& nd = sym.nodes_[t];
     GNode& g = nodes[t];
     g.off = off;
     g.woff = woff;
+    g.loff = loff;
+    loff += (long long)((nd.ns + PB - 1) / PB) * 2 * PB * PB;
     g.nf = nd.nf();
     g.ns = nd.ns;
     g.first = nd.first;
@@ -337,26 +393,35 @@ void GpuChol::build(const MfChol& sym) {
     lists.insert(lists.end(), mine.begin(), mine.end());
     hp.nodes.cnt = (int)mine.size();
     for (int s = 0; s < 2; ++s) {
-      hp.ea[s].ofs = (int)lists.size();
-      for (int t : mine)
-        if (nodes[t].child[s] >= 0 && nodes[nodes[t].child[s]].nf > nodes[nodes[t].child[s]].ns)
-          lists.push_back(nodes[t].child[s]);
-      hp.ea[s].cnt = (int)lists.size() - hp.ea[s].ofs;
+      hp.ea[s].ofs = (int)tiles.size();
+      for (int t : mine) {
+        const int c = nodes[t].child[s];
+        if (c < 0) continue;
+        const int nb = nodes[c].nf - nodes[c].ns;
+        for (int ch = 0; ch * EA_COLS < nb; ++ch) tiles.push_back({c, (short)ch, 0});
+      }
+      hp.ea[s].cnt = (int)tiles.size() - hp.ea[s].ofs;
       if (hp.ea[s].cnt) launches_++;
     }
     const int npanel = (max_ns + PB - 1) / PB;
     for (int p = 0; p < npanel; ++p) {
-      Range rn{(int)lists.size(), 0}, rt{(int)tiles.size(), 0};
+      Range rn{(int)tiles.size(), 0};
       for (int t : mine)
         if (nodes[t].ns > p * PB) {
-          lists.push_back(t);
+          const int k1 = std::min(nodes[t].ns, (p + 1) * PB);
+          const int nsl = std::max(1, (nodes[t].nf - k1 + SLICE - 1) / SLICE);
+          for (int sl = 0; sl < nsl; ++sl) tiles.push_back({t, (short)sl, 0});
+        }
+      rn.cnt = (int)tiles.size() - rn.ofs;
+      Range rt{(int)tiles.size(), 0};
+      for (int t : mine)
+        if (nodes[t].ns > p * PB) {
           const int k1 = std::min(nodes[t].ns, (p + 1) * PB);
           const int T = (nodes[t].nf - k1 + PB - 1) / PB;
           if (T > 30000) throw std::runtime_error("gpuchol: front too large for tile index");
           for (int ti = 0; ti < T; ++ti)
             for (int tj = 0; tj <= ti; ++tj) tiles.push_back({t, (short)ti, (short)tj});
         }
-      rn.cnt = (int)lists.size() - rn.ofs;
       rt.cnt = (int)tiles.size() - rt.ofs;
       hp.panel_nodes.push_back(rn);
       hp.panel_tiles.push_back(rt);
@@ -374,6 +439,8 @@ void GpuChol::build(const MfChol& sym) {
   d_tiles_ = upload(tiles);
   ck(hipMalloc((void**)&d_fronts_, std::max<long long>(total_front_, 1) * sizeof(double)), "hipMalloc fronts");
   allocs_.push_back(d_fronts_);
+  ck(hipMalloc((void**)&d_linv_, std::max<long long>(loff, 1) * sizeof(double)), "hipMalloc linv");
+  allocs_.push_back(d_linv_);
   ck(hipMalloc((void**)&d_work_, std::max<long long>(total_w_, 1) * sizeof(double)), "hipMalloc work");
   allocs_.push_back(d_work_);
   ck(hipMalloc((void**)&d_y_, std::max(n_, 1) * sizeof(double)), "hipMalloc y");
@@ -383,8 +450,10 @@ void GpuChol::build(const MfChol& sym) {
   ck(hipMemset(d_fail_, 0, sizeof(int)), "memset");
   static bool attr_done = false;
   if (!attr_done) {
-    ck(hipFuncSetAttribute((const void*)forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
-    ck(hipFuncSetAttribute((const void*)backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
+    ck(hipFuncSetAttribute((const void*)forward_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
+    ck(hipFuncSetAttribute((const void*)backward_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
+    ck(hipFuncSetAttribute((const void*)forward_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
+    ck(hipFuncSetAttribute((const void*)backward_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
     attr_done = true;
   }
 }
@@ -399,11 +468,11 @@ void GpuChol::factor(hipStream_t st, const double* d_vals) {
     const HeightPlan& hp = plan_[h];
     for (int s = 0; s < 2; ++s)
       if (hp.ea[s].cnt)
-        hipLaunchKernelGGL(extend_add_kernel, dim3(hp.ea[s].cnt), dim3(TB), 0, st, d_nodes_, d_lists_ + hp.ea[s].ofs,
+        hipLaunchKernelGGL(extend_add_kernel, dim3(hp.ea[s].cnt), dim3(TB), 0, st, d_nodes_, d_tiles_ + hp.ea[s].ofs,
                            d_ea_, d_fronts_);
     for (size_t p = 0; p < hp.panel_nodes.size(); ++p) {
       hipLaunchKernelGGL(panel_factor_kernel, dim3(hp.panel_nodes[p].cnt), dim3(TB), 0, st, d_nodes_,
-                         d_lists_ + hp.panel_nodes[p].ofs, (int)p, d_fronts_, d_fail_);
+                         d_tiles_ + hp.panel_nodes[p].ofs, (int)p, d_fronts_, d_linv_, d_fail_);
       if (hp.panel_tiles[p].cnt)
         hipLaunchKernelGGL(trailing_update_kernel, dim3(hp.panel_tiles[p].cnt), dim3(TB), 0, st, d_nodes_,
                            d_tiles_ + hp.panel_tiles[p].ofs, (int)p, d_fronts_);
@@ -417,13 +486,21 @@ void GpuChol::solve(hipStream_t st, const double* d_b, double* d_x) {
   hipLaunchKernelGGL(gather_perm_kernel, dim3(blocks_for(n_)), dim3(TB), 0, st, n_, d_perm_, d_b, d_y_);
   for (int h = 0; h < nheights_; ++h) {
     const HeightPlan& hp = plan_[h];
-    hipLaunchKernelGGL(forward_kernel, dim3(hp.nodes.cnt), dim3(TB), (size_t)hp.max_nf * sizeof(double), st, d_nodes_,
-                       d_lists_ + hp.nodes.ofs, d_ea_, d_fronts_, d_y_, d_work_);
+    if (hp.max_nf > 384)
+      hipLaunchKernelGGL(forward_kernel<1024>, dim3(hp.nodes.cnt), dim3(1024), (size_t)hp.max_nf * sizeof(double), st,
+                         d_nodes_, d_lists_ + hp.nodes.ofs, d_ea_, d_fronts_, d_linv_, d_y_, d_work_);
+    else
+      hipLaunchKernelGGL(forward_kernel<256>, dim3(hp.nodes.cnt), dim3(256), (size_t)hp.max_nf * sizeof(double), st,
+                         d_nodes_, d_lists_ + hp.nodes.ofs, d_ea_, d_fronts_, d_linv_, d_y_, d_work_);
   }
   for (int h = nheights_ - 1; h >= 0; --h) {
     const HeightPlan& hp = plan_[h];
-    hipLaunchKernelGGL(backward_kernel, dim3(hp.nodes.cnt), dim3(TB), (size_t)hp.max_nf * sizeof(double), st, d_nodes_,
-                       d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_y_);
+    if (hp.max_nf > 384)
+      hipLaunchKernelGGL(backward_kernel<1024>, dim3(hp.nodes.cnt), dim3(1024), (size_t)hp.max_nf * sizeof(double), st,
+                         d_nodes_, d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_linv_, d_y_);
+    else
+      hipLaunchKernelGGL(backward_kernel<256>, dim3(hp.nodes.cnt), dim3(256), (size_t)hp.max_nf * sizeof(double), st,
+                         d_nodes_, d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_linv_, d_y_);
   }
   hipLaunchKernelGGL(scatter_perm_kernel, dim3(blocks_for(n_)), dim3(TB), 0, st, n_, d_perm_, d_y_, d_x);
   ck(hipGetLastError(), "solve launches");

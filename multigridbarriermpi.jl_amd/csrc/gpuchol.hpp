@@ -10,7 +10,7 @@
 //   forward sweep by height (front-local right-hand sides, children pulled in fixed order)
 //   backward sweep by height.
 // Everything is gather/pull form: no atomics, bitwise reproducible.  The inverse of every 32x32
-// diagonal block of L is kept in the unused upper triangle of its front so the sweeps are mat-vecs.
+// diagonal block of L is kept in a side buffer so the sweeps are mat-vecs.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -23,6 +23,7 @@ namespace mgb {
 struct GNode {
   long long off;      // offset of the nf x nf column-major front
   long long woff;     // offset of the nf-long front-local work vector
+  long long loff;     // offset of this node's block inverses: per panel [Linv | Linv'] (2*32*32 doubles)
   int nf, ns, first, parent;
   int bofs;           // offset of this node's bdry / ea lists (nb entries each)
   int child[2];       // -1 if absent
@@ -60,6 +61,7 @@ class GpuChol {
   // device
   double* d_fronts_ = nullptr;
   double* d_work_ = nullptr;      // front-local vectors
+  double* d_linv_ = nullptr;      // inverses of the 32x32 diagonal blocks of L
   double* d_y_ = nullptr;         // permuted rhs / solution
   int* d_fail_ = nullptr;
   GNode* d_nodes_ = nullptr;
