@@ -259,31 +259,50 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
   hip_check(hipMemsetAsync(c_.p, 0, c_.n * sizeof(double), ctx_.stream), "memset");
   hip_check(hipMemsetAsync(z_.p, 0, z_.n * sizeof(double), ctx_.stream), "memset");
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
-  const int L = g.L;
-  for (int l = 0; l < L; ++l) {
+  // levels are materialised on first use (the default schedule only ever touches the finest one)
+  geo_ = g;
+  dstack_host_ = std::move(Dstack);
+  for (int l = 0; l < g.L; ++l) {
     levels_.emplace_back(new Level);
-    Level& lv = *levels_[l];
-    lv.plan = build_level_plan(g, spec, Dstack, l, P);
-    lv.R.upload(lv.plan.R);
-    lv.B.upload(lv.plan.B);
-    lv.BT.upload(lv.plan.BT);
-    lv.T.upload(lv.plan.T);
-    lv.chol.analyze(lv.plan.Apat, lv.plan.coords.data(), g.dim);
-    lv.gchol.build(lv.chol);
-    const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
-    lv.s.alloc(N);
-    lv.s_trial.alloc(N);
-    lv.s_trial2.alloc(N);
-    lv.g_trial.alloc(N);
-    lv.g.alloc(N);
-    lv.nstep.alloc(N);
-    lv.avals.alloc(nnzA);
-    lv.h_avals.alloc(nnzA);
-    lv.h_g.alloc(N);
-    lv.h_n.alloc(N);
-    lv.h_s.alloc(N);
+    int N = 0;
+    for (auto& sv : spec.state_variables) {
+      auto it = g.subspaces.find(sv.second);
+      if (it == g.subspaces.end() || l >= (int)it->second.size())
+        throw std::runtime_error("amg: unknown subspace '" + sv.second + "'");
+      N += it->second[l].cols;
+    }
+    levels_[l]->plan.N = N;
   }
 }
+
+Amg::Level& Amg::level(int l) {
+  Level& lv = *levels_.at(l);
+  if (lv.built) return lv;
+  hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
+  lv.plan = build_level_plan(geo_, spec_, dstack_host_, l, P_);
+  lv.R.upload(lv.plan.R);
+  lv.B.upload(lv.plan.B);
+  lv.BT.upload(lv.plan.BT);
+  lv.T.upload(lv.plan.T);
+  lv.chol.analyze(lv.plan.Apat, lv.plan.coords.data(), geo_.dim);
+  lv.gchol.build(lv.chol);
+  const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
+  lv.s.alloc(N);
+  lv.s_trial.alloc(N);
+  lv.s_trial2.alloc(N);
+  lv.g_trial.alloc(N);
+  lv.g.alloc(N);
+  lv.nstep.alloc(N);
+  lv.avals.alloc(nnzA);
+  lv.h_avals.alloc(nnzA);
+  lv.h_g.alloc(N);
+  lv.h_n.alloc(N);
+  lv.h_s.alloc(N);
+  lv.built = true;
+  return lv;
+}
+
+const LevelPlan& Amg::plan(int l) { return level(l).plan; }
 
 void Amg::set_c(const double* c_host) { c_.upload(c_host, (size_t)n_ * P_.K); }
 
@@ -413,8 +432,9 @@ bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st,
       hip_check(hipEventCreate(&e1), "event");
       hip_check(hipEventRecord(e0, ctx_.stream), "record");
     }
-    lv.gchol.factor(ctx_.stream, lv.avals.p);
-    lv.gchol.solve(ctx_.stream, lv.g.p, lv.nstep.p);
+    KernelTimer* tm = (live_ && (st.n_factor % 8) == 1) ? &timer_ : nullptr;
+    lv.gchol.factor(ctx_.stream, lv.avals.p, tm);
+    lv.gchol.solve(ctx_.stream, lv.g.p, lv.nstep.p, tm);
     if (live_) hip_check(hipEventRecord(e1, ctx_.stream), "record");
     launch_dot(ctx_.stream, N, lv.g.p, lv.nstep.p, partials_.p, scal_.p + 3);
     hip_check(hipMemcpyAsync(h_scal_.p + 3, scal_.p + 3, sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H inc");
@@ -452,7 +472,7 @@ static const double kBeta = 0.5, kArmijo = 0.1, kMinStep = 1e-8;
 // linesearch_backtracking() (REFINE = True) statement by statement.
 
 Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int maxit, SolveStats& st, int verbose) {
-  Level& lv = *levels_[l];
+  Level& lv = level(l);
   const int N = lv.plan.N;
   NewtonResult res;
   if (N == 0) {
@@ -570,7 +590,7 @@ bool Amg::amgb_step(double t, double lam_tol, int max_newton, std::vector<long l
   bool converged = true;
   // level schedule: finest level only (default) or the literal coarse -> fine loop (oracle LEVEL_SCHEDULE)
   for (int J = (schedule_all_ ? 0 : L - 1); J < L; ++J) {
-    Level& lv = *levels_[J];
+    Level& lv = level(J);
     NewtonResult r = newton(J, t, J == L - 1, lam_tol, max_newton, st, verbose);
     its[J] += r.k;
     if (lv.plan.N > 0) {
@@ -660,13 +680,13 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
 // ------------------------------------------------------------------ fine-grained entry points
 
 double Amg::f0(int l, const double* s_host, double t, double* parts) {
-  Level& lv = *levels_.at(l);
+  Level& lv = level(l);
   lv.s_trial.upload(s_host, lv.plan.N);
   return dev_f0(lv, lv.s_trial.p, t, parts, nullptr, phi_cur_.p);
 }
 
 double Amg::f0_trial(int l, const double* s_ref_host, const double* s_host, double t) {
-  Level& lv = *levels_.at(l);
+  Level& lv = level(l);
   lv.s_trial.upload(s_ref_host, lv.plan.N);
   dev_f0(lv, lv.s_trial.p, t, nullptr, nullptr, phi_cur_.p);     // records phi of the reference iterate
   lv.s_trial.upload(s_host, lv.plan.N);
@@ -674,7 +694,7 @@ double Amg::f0_trial(int l, const double* s_ref_host, const double* s_host, doub
 }
 
 void Amg::f1(int l, const double* s_host, double t, double* g_host) {
-  Level& lv = *levels_.at(l);
+  Level& lv = level(l);
   lv.s_trial.upload(s_host, lv.plan.N);
   dev_f1(lv, lv.s_trial.p, t, false, lv.g_trial.p);
   lv.g_trial.download(g_host, lv.plan.N);
@@ -682,7 +702,7 @@ void Amg::f1(int l, const double* s_host, double t, double* g_host) {
 
 void Amg::f2(int l, const double* s_host, double t, double* avals_host) {
   (void)t;
-  Level& lv = *levels_.at(l);
+  Level& lv = level(l);
   lv.s_trial.upload(s_host, lv.plan.N);
   dev_apply(lv, lv.s_trial.p);
   launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p);
@@ -692,7 +712,7 @@ void Amg::f2(int l, const double* s_host, double t, double* avals_host) {
 }
 
 void Amg::apply_D(int l, const double* s_host, double* Dz_host) {
-  Level& lv = *levels_.at(l);
+  Level& lv = level(l);
   lv.s_trial.upload(s_host, lv.plan.N);
   dev_apply(lv, lv.s_trial.p);
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
@@ -700,7 +720,7 @@ void Amg::apply_D(int l, const double* s_host, double* Dz_host) {
 }
 
 bool Amg::solve_device(int l, const double* avals, const double* g, double* nstep) {
-  Level& lv = *levels_.at(l);
+  Level& lv = level(l);
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   lv.avals.upload(avals, lv.plan.Apat.nnz());
   lv.g_trial.upload(g, lv.plan.N);
@@ -713,7 +733,7 @@ bool Amg::solve_device(int l, const double* avals, const double* g, double* nste
 }
 
 bool Amg::solve_host(int l, const double* avals, const double* g, double* nstep) {
-  Level& lv = *levels_.at(l);
+  Level& lv = level(l);
   if (!lv.chol.factor(avals)) return false;
   std::copy(g, g + lv.plan.N, nstep);
   lv.chol.solve(nstep);
@@ -721,7 +741,7 @@ bool Amg::solve_host(int l, const double* avals, const double* g, double* nstep)
 }
 
 Amg::KernelTimes Amg::time_kernels(int l, int reps) {
-  Level& lv = *levels_.at(l);
+  Level& lv = level(l);
   KernelTimes kt{};
   hipEvent_t e0, e1;
   hip_check(hipEventCreate(&e0), "event");

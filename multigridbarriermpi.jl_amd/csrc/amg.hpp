@@ -107,6 +107,13 @@ Csr build_dstack(const GeometryHost& g, const AmgSpec& spec);
 LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr& Dstack, int level,
                            const BarrierParams& P);
 
+// kernel classes timed live with HIP events (KernelTimer); the Cholesky classes are sampled on every 8th
+// factorisation to keep the event overhead below 1 %
+enum KernelClass {
+  KC_APPLY = 0, KC_F2 = 1, KC_ASSEMBLE = 2, KC_F1 = 3, KC_RESTRICT = 4, KC_F0 = 5,
+  KC_CHOL_PANEL = 6, KC_CHOL_TRAIL = 7, KC_CHOL_EXTEND = 8, KC_CHOL_FWD = 9, KC_CHOL_BWD = 10, KC_COUNT = 11
+};
+
 constexpr double kFracToBoundary = 0.1;   // == oracle FRAC_TO_BOUNDARY
 
 struct SolveOptions {
@@ -129,12 +136,10 @@ struct SolveStats {
   double time_factor = 0, time_device = 0;
   long long n_factor = 0, n_f0 = 0, n_f1 = 0, n_f2 = 0;
   // live HIP-event timing of the six kernel classes over the solve (KernelClass order)
-  double kern_ms[6] = {0, 0, 0, 0, 0, 0};
-  double kern_bytes[6] = {0, 0, 0, 0, 0, 0};
-  long long kern_launches[6] = {0, 0, 0, 0, 0, 0};
+  double kern_ms[KC_COUNT] = {};
+  double kern_bytes[KC_COUNT] = {};
+  long long kern_launches[KC_COUNT] = {};
 };
-
-enum KernelClass { KC_APPLY = 0, KC_F2 = 1, KC_ASSEMBLE = 2, KC_F1 = 3, KC_RESTRICT = 4, KC_F0 = 5 };
 
 // Event-pair pool: brackets single kernel launches on the context stream; resolved at host syncs.
 class KernelTimer {
@@ -163,7 +168,7 @@ class Amg {
   int K() const { return P_.K; }
   int L() const { return (int)levels_.size(); }
   int level_size(int l) const { return levels_[l]->plan.N; }
-  const LevelPlan& plan(int l) const { return levels_[l]->plan; }
+  const LevelPlan& plan(int l);   // builds the level on first use
   const BarrierParams& params() const { return P_; }
 
   // problem data: c is n x K row-major, z is the S*n vector [u; s]
@@ -197,6 +202,7 @@ class Amg {
 
  private:
   struct Level {
+    bool built = false;
     LevelPlan plan;
     DevCsrOwned R, B, BT, T;
     MfChol chol;      // symbolic structure (+ host numeric path)
@@ -208,6 +214,7 @@ class Amg {
     int k = 0;
     bool converged = false;
   };
+  Level& level(int l);            // lazily built
   void refresh_dz0();
   void dev_apply(Level& lv, const double* s_dev);                 // Dz = Dz0 + B s
   double dev_f0(Level& lv, const double* s_dev, double t, double* parts, const double* phi_ref, double* phi_out);
@@ -221,6 +228,8 @@ class Amg {
   int n_ = 0, S_ = 0;
   BarrierParams P_;
   AmgSpec spec_;
+  GeometryHost geo_;              // kept for lazy level construction
+  Csr dstack_host_;
   DevCsrOwned Dstack_;
   std::vector<std::unique_ptr<Level>> levels_;
   DevBuf<double> w_, c_, z_, z_save_, Dz0_, Dz0_save_, Dz_, v_, Y_, partials_, scal_, phi_cur_, phi_trial_, phi_trial2_;

@@ -567,13 +567,13 @@ int mgb_amg_sol_get(mgb_amg a, long long* its, double* ts, double* c_dot_Dz) {
     if (c_dot_Dz) std::copy(a->stats.c_dot_Dz.begin(), a->stats.c_dot_Dz.end(), c_dot_Dz);
   });
 }
-int mgb_amg_sol_kernels(mgb_amg a, double* ms6, double* bytes6, long long* launches6) {
+int mgb_amg_sol_kernels(mgb_amg a, double* ms11, double* bytes11, long long* launches11) {
   return guard([&] {
     need(a, "null amg");
-    for (int i = 0; i < 6; ++i) {
-      if (ms6) ms6[i] = a->stats.kern_ms[i];
-      if (bytes6) bytes6[i] = a->stats.kern_bytes[i];
-      if (launches6) launches6[i] = a->stats.kern_launches[i];
+    for (int i = 0; i < KC_COUNT; ++i) {
+      if (ms11) ms11[i] = a->stats.kern_ms[i];
+      if (bytes11) bytes11[i] = a->stats.kern_bytes[i];
+      if (launches11) launches11[i] = a->stats.kern_launches[i];
     }
   });
 }

@@ -6,6 +6,8 @@
 // Cache; no MFMA (fp64 dense work is small and triangular/ragged).
 #include "gpuchol.hpp"
 
+#include "amg.hpp"
+
 #include <algorithm>
 #include <cmath>
 #include <stdexcept>
@@ -392,12 +394,16 @@ void GpuChol::build(const MfChol& sym) {
       }
     lists.insert(lists.end(), mine.begin(), mine.end());
     hp.nodes.cnt = (int)mine.size();
+    hp.sweep_bytes = 0;
+    for (int t : mine) hp.sweep_bytes += ((double)nodes[t].nf * nodes[t].ns - 0.5 * nodes[t].ns * nodes[t].ns) * 8 + nodes[t].nf * 24.0;
     for (int s = 0; s < 2; ++s) {
       hp.ea[s].ofs = (int)tiles.size();
+      hp.ea_bytes[s] = 0;
       for (int t : mine) {
         const int c = nodes[t].child[s];
         if (c < 0) continue;
         const int nb = nodes[c].nf - nodes[c].ns;
+        hp.ea_bytes[s] += 0.5 * nb * nb * 24.0;     // read child entry, read+write parent entry
         for (int ch = 0; ch * EA_COLS < nb; ++ch) tiles.push_back({c, (short)ch, 0});
       }
       hp.ea[s].cnt = (int)tiles.size() - hp.ea[s].ofs;
@@ -406,9 +412,11 @@ void GpuChol::build(const MfChol& sym) {
     const int npanel = (max_ns + PB - 1) / PB;
     for (int p = 0; p < npanel; ++p) {
       Range rn{(int)tiles.size(), 0};
+      double pbytes = 0;
       for (int t : mine)
         if (nodes[t].ns > p * PB) {
           const int k1 = std::min(nodes[t].ns, (p + 1) * PB);
+          pbytes += ((double)(nodes[t].nf - p * PB) * (k1 - p * PB)) * 16.0;   // panel read + written once
           const int nsl = std::max(1, (nodes[t].nf - k1 + SLICE - 1) / SLICE);
           for (int sl = 0; sl < nsl; ++sl) tiles.push_back({t, (short)sl, 0});
         }
@@ -424,6 +432,7 @@ void GpuChol::build(const MfChol& sym) {
         }
       rt.cnt = (int)tiles.size() - rt.ofs;
       hp.panel_nodes.push_back(rn);
+      hp.panel_bytes.push_back(pbytes);
       hp.panel_tiles.push_back(rt);
       launches_ += 1 + (rt.cnt ? 1 : 0);
     }
@@ -458,7 +467,7 @@ void GpuChol::build(const MfChol& sym) {
   }
 }
 
-void GpuChol::factor(hipStream_t st, const double* d_vals) {
+void GpuChol::factor(hipStream_t st, const double* d_vals, KernelTimer* tm) {
   if (n_ == 0) return;
   ck(hipMemsetAsync(d_fronts_, 0, total_front_ * sizeof(double), st), "memset fronts");
   ck(hipMemsetAsync(d_fail_, 0, sizeof(int), st), "memset flag");
@@ -467,40 +476,52 @@ void GpuChol::factor(hipStream_t st, const double* d_vals) {
   for (int h = 0; h < nheights_; ++h) {
     const HeightPlan& hp = plan_[h];
     for (int s = 0; s < 2; ++s)
-      if (hp.ea[s].cnt)
+      if (hp.ea[s].cnt) {
+        if (tm) tm->begin(st, KC_CHOL_EXTEND, hp.ea_bytes[s]);
         hipLaunchKernelGGL(extend_add_kernel, dim3(hp.ea[s].cnt), dim3(TB), 0, st, d_nodes_, d_tiles_ + hp.ea[s].ofs,
                            d_ea_, d_fronts_);
+        if (tm) tm->end(st);
+      }
     for (size_t p = 0; p < hp.panel_nodes.size(); ++p) {
+      if (tm) tm->begin(st, KC_CHOL_PANEL, hp.panel_bytes[p]);
       hipLaunchKernelGGL(panel_factor_kernel, dim3(hp.panel_nodes[p].cnt), dim3(TB), 0, st, d_nodes_,
                          d_tiles_ + hp.panel_nodes[p].ofs, (int)p, d_fronts_, d_linv_, d_fail_);
-      if (hp.panel_tiles[p].cnt)
+      if (tm) tm->end(st);
+      if (hp.panel_tiles[p].cnt) {
+        if (tm) tm->begin(st, KC_CHOL_TRAIL, hp.panel_tiles[p].cnt * 32768.0);   // 2 panel tiles + C read/write
         hipLaunchKernelGGL(trailing_update_kernel, dim3(hp.panel_tiles[p].cnt), dim3(TB), 0, st, d_nodes_,
                            d_tiles_ + hp.panel_tiles[p].ofs, (int)p, d_fronts_);
+        if (tm) tm->end(st);
+      }
     }
   }
   ck(hipGetLastError(), "factor launches");
 }
 
-void GpuChol::solve(hipStream_t st, const double* d_b, double* d_x) {
+void GpuChol::solve(hipStream_t st, const double* d_b, double* d_x, KernelTimer* tm) {
   if (n_ == 0) return;
   hipLaunchKernelGGL(gather_perm_kernel, dim3(blocks_for(n_)), dim3(TB), 0, st, n_, d_perm_, d_b, d_y_);
   for (int h = 0; h < nheights_; ++h) {
     const HeightPlan& hp = plan_[h];
+    if (tm) tm->begin(st, KC_CHOL_FWD, hp.sweep_bytes);
     if (hp.max_nf > 384)
       hipLaunchKernelGGL(forward_kernel<1024>, dim3(hp.nodes.cnt), dim3(1024), (size_t)hp.max_nf * sizeof(double), st,
                          d_nodes_, d_lists_ + hp.nodes.ofs, d_ea_, d_fronts_, d_linv_, d_y_, d_work_);
     else
       hipLaunchKernelGGL(forward_kernel<256>, dim3(hp.nodes.cnt), dim3(256), (size_t)hp.max_nf * sizeof(double), st,
                          d_nodes_, d_lists_ + hp.nodes.ofs, d_ea_, d_fronts_, d_linv_, d_y_, d_work_);
+    if (tm) tm->end(st);
   }
   for (int h = nheights_ - 1; h >= 0; --h) {
     const HeightPlan& hp = plan_[h];
+    if (tm) tm->begin(st, KC_CHOL_BWD, hp.sweep_bytes);
     if (hp.max_nf > 384)
       hipLaunchKernelGGL(backward_kernel<1024>, dim3(hp.nodes.cnt), dim3(1024), (size_t)hp.max_nf * sizeof(double), st,
                          d_nodes_, d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_linv_, d_y_);
     else
       hipLaunchKernelGGL(backward_kernel<256>, dim3(hp.nodes.cnt), dim3(256), (size_t)hp.max_nf * sizeof(double), st,
                          d_nodes_, d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_linv_, d_y_);
+    if (tm) tm->end(st);
   }
   hipLaunchKernelGGL(scatter_perm_kernel, dim3(blocks_for(n_)), dim3(TB), 0, st, n_, d_perm_, d_y_, d_x);
   ck(hipGetLastError(), "solve launches");

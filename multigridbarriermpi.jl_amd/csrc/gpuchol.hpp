@@ -20,6 +20,8 @@
 
 namespace mgb {
 
+class KernelTimer;   // amg.hpp: optional HIP-event bracketing of individual launches
+
 struct GNode {
   long long off;      // offset of the nf x nf column-major front
   long long woff;     // offset of the nf-long front-local work vector
@@ -42,9 +44,9 @@ class GpuChol {
   ~GpuChol();
   void build(const MfChol& sym);
   // d_vals: device lower-triangle values in the pattern order given to MfChol::analyze
-  void factor(hipStream_t st, const double* d_vals);
+  void factor(hipStream_t st, const double* d_vals, KernelTimer* timer = nullptr);
   // d_x = A^{-1} d_b, both device vectors in the ORIGINAL ordering (may alias)
-  void solve(hipStream_t st, const double* d_b, double* d_x);
+  void solve(hipStream_t st, const double* d_b, double* d_x, KernelTimer* timer = nullptr);
   int* fail_flag() const { return d_fail_; }   // device int: nonzero after factor() if a pivot was not positive
   int size() const { return n_; }
   double front_bytes() const { return (double)total_front_ * 8; }
@@ -80,6 +82,8 @@ class GpuChol {
     Range nodes;
     Range ea[2];
     std::vector<Range> panel_nodes, panel_tiles;
+    std::vector<double> panel_bytes;
+    double ea_bytes[2], sweep_bytes;
     int max_nf;
   };
   std::vector<HeightPlan> plan_;
