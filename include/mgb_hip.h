@@ -82,7 +82,7 @@ int mgb_all_isfinite(mgb_vec x, int* out);                    /* amgb_all_isfini
  * state_vars: S pairs "name\0subspace\0" flattened as 2*S C strings; D: K pairs (state var, operator)
  * (amg(geometry; state_variables, D): layout test/test_d0_construction.jl:82-100).
  * Barrier: power cone {(q,s): s >= |q|^p} on D rows idx_q[0..nq) and idx_s (convex_Euclidian_power).
- * Uploads the geometry to HBM (the native_to_mpi step, src:259-338) and builds every level. */
+ * Uploads the geometry to HBM (the native_to_mpi step, src:259-338); levels are built on first use. */
 int mgb_amg_create(mgb_ctx ctx, mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D,
                    int nq, const int* idx_q, int idx_s, double p, mgb_amg* out);
 int mgb_amg_destroy(mgb_amg a);
