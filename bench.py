@@ -58,6 +58,21 @@ def cpu_baseline(L, p, budget_s):
                        "coarse->fine, scipy SuperLU solves), %.1f s" % (steps, Lc, p, dt))
 
 
+def max_over_ranks(elapsed, dist=None, device="cpu"):
+    """Slowest rank's wall time (the contract's MAX over ranks); identity when not distributed."""
+    if dist is None:
+        return float(elapsed)
+    import torch
+    tt = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def whole_job_value(n, newton_steps_per_rank, world, elapsed):
+    """Replicas: every rank runs the same workload, so the job processed world * n * steps DoF-steps."""
+    return world * n * newton_steps_per_rank / elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,14 +141,12 @@ def main():
     backend.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed, dist, "cuda")
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
         dist.barrier()
 
     newton_steps = int(sum(int(s["its"].sum()) for s in sols))
-    value = world * n * newton_steps / elapsed
+    value = whole_job_value(n, newton_steps, world, elapsed)
     if rank == 0:
         last = sols[-1]
         kern = {}

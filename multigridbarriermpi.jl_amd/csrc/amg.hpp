@@ -115,6 +115,7 @@ enum KernelClass {
 };
 
 constexpr double kFracToBoundary = 0.1;   // == oracle FRAC_TO_BOUNDARY
+constexpr double kKappaGrowFrac = 0.25;   // == oracle KAPPA_GROW_FRAC
 
 struct SolveOptions {
   bool host_solve = false;              // true: factor/solve on the host (MfChol), false: on the GPU (GpuChol)

@@ -458,6 +458,7 @@ def hessian_recipe(D, w, y, R=None):
 BETA = 0.5          # backtracking factor
 ARMIJO = 0.1        # sufficient-decrease constant
 MIN_STEP = 1e-8     # give up the line search below this step length
+KAPPA_GROW_FRAC = 0.25  # kappa grows back (kappa <- min(kappa0, kappa^2)) only after a centering with <= 25 % of max_newton
 REFINE = True       # after the first acceptable step keep halving while the objective improves
 FRAC_TO_BOUNDARY = 0.1  # a step may not shrink any row's cone distance phi below this fraction of its value
 
@@ -599,7 +600,7 @@ def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max
             SOL = amgb_step(B, M, z, Dz0, t1 * c, max_newton, lam_tol, log, schedule)
             it_k += SOL["its"]
             if SOL["converged"]:
-                if SOL["its"].max() <= max_newton * 0.5:
+                if SOL["its"].max() <= max_newton * KAPPA_GROW_FRAC:
                     kappa = min(kappa0, kappa * kappa)
                 z, Dz0, t = SOL["z"], SOL["Dz0"], t1
                 break
