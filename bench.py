@@ -159,8 +159,17 @@ def main():
         dom = max(est, key=lambda k: est[k])
         kd = kern[dom]
         achieved = kd["bytes"] / max(kd["ms"], 1e-12) / 1e6      # GB/s = bytes / ms / 1e6
+        # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # runs of this same command, gfx950 FETCH_SIZE x2 correction applied); null for other workloads
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            if pmc.get("workload") == "fem2d L=%d p=%g" % (args.L, args.p):
+                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None,
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                         avg_launch_us=1e3 * kd["ms"] / max(kd["launches"], 1), launches_timed=kd["launches"],
                         algorithmic_bytes_per_launch=kd["bytes"] / max(kd["launches"], 1),
                         note="latency-bound at this size: every working set is L2/Infinity-Cache resident and the "
