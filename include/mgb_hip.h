@@ -49,6 +49,8 @@ int mgb_ctx_synchronize(mgb_ctx ctx);
  * native_to_mpi.  K: 3m x 2 row-major coarse triangle vertices or NULL for the default square. */
 int mgb_fem1d_native(int L, mgb_geo* out);
 int mgb_fem2d_native(int L, const double* K, int nK_rows, mgb_geo* out);
+/* fem3d (called at src:698): Q_k hexahedra on the default cube, k = 1..3 (reference default k = 3, src:682-684) */
+int mgb_fem3d_native(int L, int k, mgb_geo* out);
 /* A Geometry assembled by the caller (native_to_mpi input, src:259-302): create, then add matrices.
  * names: "op:<key>" (n x n), "sub:<key>:<level>" (n x m_l, level 0 = coarsest),
  *        "refine:<level>", "coarsen:<level>".  block = rows per element (1 if unknown). */

@@ -31,7 +31,8 @@ from ._lib import MGBError, call, dptr, f64, i32, iptr
 import ctypes as C
 
 __all__ = [
-    "fem1d", "fem2d", "fem1d_mpi", "fem2d_mpi", "fem1d_mpi_solve", "fem2d_mpi_solve", "native_to_mpi",
+    "fem1d", "fem2d", "fem3d", "fem1d_mpi", "fem2d_mpi", "fem3d_mpi", "fem1d_mpi_solve", "fem2d_mpi_solve",
+    "fem3d_mpi_solve", "native_to_mpi",
     "mpi_to_native", "amgb", "Geometry", "AMGBSOL", "HPCVector", "HPCMatrix", "HPCSparseMatrix",
     "backend_hip", "amgb_zeros", "amgb_all_isfinite", "amgb_diag", "amgb_blockdiag", "map_rows", "map_rows_gpu",
     "_raw_array", "_to_cpu_array", "MGBError", "device_count", "AMG", "amg",
@@ -387,6 +388,23 @@ def fem1d_mpi(L: int = 4, Ti=np.int32, backend=None) -> Geometry:
     return native_to_mpi(fem1d(L), Ti=Ti, backend=backend)
 
 
+def fem3d(L: int = 2, k: int = 3) -> Geometry:
+    """Native 3-D geometry (MultiGridBarrier.fem3d, called at src:698): Q_k hexahedra, k = 3 default."""
+    h = C.c_void_p()
+    call("mgb_fem3d_native", int(L), int(k), C.byref(h))
+    try:
+        g = _native_from_handle(h, "fem3d", ("id", "dx", "dy", "dz"))
+        g.discretization["k"] = int(k)
+        return g
+    finally:
+        call("mgb_geo_destroy", h)
+
+
+def fem3d_mpi(L: int = 2, k: int = 3, Ti=np.int32, backend=None) -> Geometry:
+    """src:696-702."""
+    return native_to_mpi(fem3d(L, k), Ti=Ti, backend=backend)
+
+
 def fem2d_mpi(L: int = 2, K=None, Ti=np.int32, backend=None) -> Geometry:
     """src:626-632."""
     return native_to_mpi(fem2d(L, K), Ti=Ti, backend=backend)
@@ -396,9 +414,12 @@ def fem2d_mpi(L: int = 2, K=None, Ti=np.int32, backend=None) -> Geometry:
 
 DEFAULT_STATE = (("u", "dirichlet"), ("s", "full"))
 DEFAULT_D = {1: (("u", "id"), ("u", "dx"), ("s", "id")),
-             2: (("u", "id"), ("u", "dx"), ("u", "dy"), ("s", "id"))}
-DEFAULT_F = {1: lambda x: np.array([0.5, 0.0, 1.0]), 2: lambda x: np.array([0.5, 0.0, 0.0, 1.0])}
-DEFAULT_G = {1: lambda x: np.array([x[0], 2.0]), 2: lambda x: np.array([x[0] ** 2 + x[1] ** 2, 100.0])}
+             2: (("u", "id"), ("u", "dx"), ("u", "dy"), ("s", "id")),
+             3: (("u", "id"), ("u", "dx"), ("u", "dy"), ("u", "dz"), ("s", "id"))}              # src:736
+DEFAULT_F = {1: lambda x: np.array([0.5, 0.0, 1.0]), 2: lambda x: np.array([0.5, 0.0, 0.0, 1.0]),
+             3: lambda x: np.array([0.5, 0.0, 0.0, 0.0, 1.0])}                                   # src:737
+DEFAULT_G = {1: lambda x: np.array([x[0], 2.0]), 2: lambda x: np.array([x[0] ** 2 + x[1] ** 2, 100.0]),
+             3: lambda x: np.array([x[0] ** 2 + x[1] ** 2 + x[2] ** 2, 100.0])}                  # src:738
 
 
 class AMG:
@@ -584,6 +605,13 @@ def fem1d_mpi_solve(L: int = 4, **kwargs) -> AMGBSOL:
     """src:594-600: kwargs go to both fem1d_mpi and amgb."""
     geo_kw = {k: kwargs[k] for k in ("Ti", "backend") if k in kwargs}
     return amgb(fem1d_mpi(L, **geo_kw), **{k: v for k, v in kwargs.items() if k not in geo_kw})
+
+
+def fem3d_mpi_solve(L: int = 2, k: int = 3, D=None, f=None, g=None, **kwargs) -> AMGBSOL:
+    """src:735-745: 3-D defaults D = [u id; u dx; u dy; u dz; s id], f = (.5,0,0,0,1), g = (|x|^2, 100)."""
+    geo_kw = {kk: kwargs[kk] for kk in ("Ti", "backend") if kk in kwargs}
+    rest = {kk: v for kk, v in kwargs.items() if kk not in geo_kw}
+    return amgb(fem3d_mpi(L, k, **geo_kw), D=D or DEFAULT_D[3], f=f or DEFAULT_F[3], g=g or DEFAULT_G[3], **rest)
 
 
 def fem2d_mpi_solve(L: int = 2, K=None, **kwargs) -> AMGBSOL:

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "mgb_ctx_synchronize": [H],
     "mgb_fem1d_native": [C.c_int, C.POINTER(H)],
     "mgb_fem2d_native": [C.c_int, c_dbl_p, C.c_int, C.POINTER(H)],
+    "mgb_fem3d_native": [C.c_int, C.c_int, C.POINTER(H)],
     "mgb_geo_create": [C.c_int, C.c_int, C.c_int, C.c_int, c_dbl_p, c_dbl_p, C.POINTER(H)],
     "mgb_geo_set_matrix": [H, C.c_char_p, C.c_int, C.c_int, c_i32_p, c_i32_p, c_dbl_p],
     "mgb_geo_destroy": [H],

@@ -214,6 +214,19 @@ int mgb_fem2d_native(int L, const double* K, int nK_rows, mgb_geo* out) {
     *out = g;
   });
 }
+int mgb_fem3d_native(int L, int k, mgb_geo* out) {
+  return guard([&] {
+    need(out, "null out");
+    auto* g = new mgb_geo_s;
+    try {
+      g->g = fem3d_native(L, k);
+    } catch (...) {
+      delete g;
+      throw;
+    }
+    *out = g;
+  });
+}
 int mgb_geo_create(int n, int dim, int L, int block, const double* x, const double* w, mgb_geo* out) {
   return guard([&] {
     need(out && x && w && n > 0 && dim >= 1 && dim <= 3 && L >= 1 && block >= 1, "geo_create: bad arguments");

@@ -331,4 +331,182 @@ GeometryHost fem2d_native(int L, const double* K, int nK_rows) {
   return g;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// 3-D broken Q_k hexahedra on [-1,1]^3 (reference: fem3d, called at src/MultiGridBarrierMPI.jl:698; "Q_k",
+// k = 3 default, src:682-684).  Equispaced tensor nodes (x fastest), Newton-Cotes tensor quadrature at the
+// nodes, octree refinement with child index cx + 2 cy + 4 cz.  The 1-D Lagrange basis is evaluated from its
+// product formula (the oracle inverts a Vandermonde matrix instead).
+namespace {
+
+struct Lag1d {
+  int k;
+  std::vector<double> xi;
+  explicit Lag1d(int k_) : k(k_), xi(k_ + 1) {
+    for (int i = 0; i <= k; ++i) xi[i] = (double)i / k;
+  }
+  double val(int j, double t) const {
+    double v = 1.0;
+    for (int m = 0; m <= k; ++m)
+      if (m != j) v *= (t - xi[m]) / (xi[j] - xi[m]);
+    return v;
+  }
+  double der(int j, double t) const {
+    double s = 0.0;
+    for (int m = 0; m <= k; ++m) {
+      if (m == j) continue;
+      double v = 1.0 / (xi[j] - xi[m]);
+      for (int r = 0; r <= k; ++r)
+        if (r != j && r != m) v *= (t - xi[r]) / (xi[j] - xi[r]);
+      s += v;
+    }
+    return s;
+  }
+};
+
+}  // namespace
+
+GeometryHost fem3d_native(int L, int k) {
+  if (L < 1 || L > 8) throw std::runtime_error("fem3d: L out of range");
+  if (k < 1 || k > 3) throw std::runtime_error("fem3d: k must be 1, 2 or 3");
+  const Lag1d lg(k);
+  const int m1 = k + 1, nloc = m1 * m1 * m1;
+  const double wq1[3][4] = {{0.5, 0.5, 0, 0}, {1.0 / 6, 4.0 / 6, 1.0 / 6, 0}, {1.0 / 8, 3.0 / 8, 3.0 / 8, 1.0 / 8}};
+  const double* wq = wq1[k - 1];
+  GeometryHost g;
+  g.dim = 3;
+  g.block = nloc;
+  g.L = L;
+  // element lower corners per level, in refinement order
+  std::vector<std::vector<std::array<int, 3>>> elems(L);
+  elems[0].push_back({0, 0, 0});
+  for (int l = 1; l < L; ++l) {
+    elems[l].reserve(elems[l - 1].size() * 8);
+    for (const auto& e : elems[l - 1])
+      for (int c = 0; c < 8; ++c) elems[l].push_back({2 * e[0] + (c & 1), 2 * e[1] + ((c >> 1) & 1), 2 * e[2] + ((c >> 2) & 1)});
+  }
+  const auto& E = elems[L - 1];
+  const int ne = (int)E.size();
+  const int ncell = 1 << (L - 1);
+  const double h = 2.0 / ncell;
+  g.n = ne * nloc;
+  g.x.resize((size_t)g.n * 3);
+  g.w.resize(g.n);
+  auto lidx = [&](int i, int j, int m) { return i + m1 * (j + m1 * m); };
+  // 1-D derivative matrix at the nodes (d/dx = (1/h) d/dxi)
+  std::vector<double> dB((size_t)m1 * m1);
+  for (int i = 0; i < m1; ++i)
+    for (int a = 0; a < m1; ++a) {
+      double v = lg.der(a, lg.xi[i]) / h;
+      dB[(size_t)i * m1 + a] = std::fabs(v) < 1e-13 / h ? 0.0 : v;
+    }
+  Csr dx(g.n, g.n), dy(g.n, g.n), dz(g.n, g.n);
+  for (int e = 0; e < ne; ++e)
+    for (int m = 0; m < m1; ++m)
+      for (int j = 0; j < m1; ++j)
+        for (int i = 0; i < m1; ++i) {
+          const int r = e * nloc + lidx(i, j, m);
+          g.x[3 * (size_t)r] = -1.0 + h * (E[e][0] + lg.xi[i]);
+          g.x[3 * (size_t)r + 1] = -1.0 + h * (E[e][1] + lg.xi[j]);
+          g.x[3 * (size_t)r + 2] = -1.0 + h * (E[e][2] + lg.xi[m]);
+          g.w[r] = wq[i] * wq[j] * wq[m] * h * h * h;
+          for (int a = 0; a < m1; ++a) {
+            if (dB[(size_t)i * m1 + a] != 0.0) {
+              dx.colidx.push_back(e * nloc + lidx(a, j, m));
+              dx.vals.push_back(dB[(size_t)i * m1 + a]);
+            }
+            if (dB[(size_t)j * m1 + a] != 0.0) {
+              dy.colidx.push_back(e * nloc + lidx(i, a, m));
+              dy.vals.push_back(dB[(size_t)j * m1 + a]);
+            }
+            if (dB[(size_t)m * m1 + a] != 0.0) {
+              dz.colidx.push_back(e * nloc + lidx(i, j, a));
+              dz.vals.push_back(dB[(size_t)m * m1 + a]);
+            }
+          }
+          dx.rowptr[r + 1] = (int)dx.colidx.size();
+          dy.rowptr[r + 1] = (int)dy.colidx.size();
+          dz.rowptr[r + 1] = (int)dz.colidx.size();
+        }
+  g.operators["dx"] = std::move(dx);
+  g.operators["dy"] = std::move(dy);
+  g.operators["dz"] = std::move(dz);
+  g.operators["id"] = identity(g.n);
+  // refine block (8 nloc x nloc) and injection (nloc x 8 nloc)
+  std::vector<double> P1((size_t)2 * m1 * m1);   // [c][i][a] = basis a at the i-th node of child c
+  for (int c = 0; c < 2; ++c)
+    for (int i = 0; i < m1; ++i)
+      for (int a = 0; a < m1; ++a) P1[((size_t)c * m1 + i) * m1 + a] = lg.val(a, 0.5 * c + 0.5 * lg.xi[i]);
+  std::vector<Triplet> pblk, iblk;
+  for (int c = 0; c < 8; ++c)
+    for (int m = 0; m < m1; ++m)
+      for (int j = 0; j < m1; ++j)
+        for (int i = 0; i < m1; ++i)
+          for (int cc = 0; cc < m1; ++cc)
+            for (int b = 0; b < m1; ++b)
+              for (int a = 0; a < m1; ++a) {
+                const double v = P1[(((size_t)(c & 1)) * m1 + i) * m1 + a] * P1[(((size_t)((c >> 1) & 1)) * m1 + j) * m1 + b] *
+                                 P1[(((size_t)((c >> 2) & 1)) * m1 + m) * m1 + cc];
+                if (std::fabs(v) >= 1e-14) pblk.push_back({c * nloc + lidx(i, j, m), lidx(a, b, cc), v});
+              }
+  for (int m = 0; m < m1; ++m)
+    for (int j = 0; j < m1; ++j)
+      for (int i = 0; i < m1; ++i) {
+        const int t[3] = {2 * i, 2 * j, 2 * m};
+        int c[3], q[3];
+        for (int d = 0; d < 3; ++d) {
+          c[d] = t[d] > k ? 1 : 0;   // ties go to child 0
+          q[d] = t[d] - c[d] * k;
+        }
+        iblk.push_back({lidx(i, j, m), (c[0] + 2 * c[1] + 4 * c[2]) * nloc + lidx(q[0], q[1], q[2]), 1.0});
+      }
+  for (int l = 0; l + 1 < L; ++l) {
+    const int nel = (int)elems[l].size();
+    std::vector<Triplet> r, cmat;
+    r.reserve(pblk.size() * nel);
+    for (int e = 0; e < nel; ++e) {
+      for (const auto& t : pblk) r.push_back({e * 8 * nloc + t.r, e * nloc + t.c, t.v});
+      for (const auto& t : iblk) cmat.push_back({e * nloc + t.r, e * 8 * nloc + t.c, 1.0});
+    }
+    g.refine.push_back(from_triplets(nel * 8 * nloc, nel * nloc, std::move(r)));
+    g.coarsen.push_back(from_triplets(nel * nloc, nel * 8 * nloc, std::move(cmat)));
+  }
+  g.refine.push_back(identity(g.n));
+  g.coarsen.push_back(identity(g.n));
+  auto& full = g.subspaces["full"];
+  auto& dir = g.subspaces["dirichlet"];
+  for (int l = 0; l < L; ++l) {
+    const auto& El = elems[l];
+    const int nel = (int)El.size();
+    const int npts = k * (1 << l) + 1;
+    const long long ntot = (long long)npts * npts * npts;
+    if (ntot > 2000000000LL) throw std::runtime_error("fem3d: too many continuous dofs for Int32");
+    std::vector<int> dmap((size_t)ntot, -1);
+    int md = 0;
+    for (int c = 0; c < npts; ++c)
+      for (int b = 0; b < npts; ++b)
+        for (int a = 0; a < npts; ++a)
+          if (a > 0 && a < npts - 1 && b > 0 && b < npts - 1 && c > 0 && c < npts - 1)
+            dmap[(size_t)a + (size_t)npts * (b + (size_t)npts * c)] = md++;
+    std::vector<Triplet> sf, sd;
+    for (int e = 0; e < nel; ++e)
+      for (int m = 0; m < m1; ++m)
+        for (int j = 0; j < m1; ++j)
+          for (int i = 0; i < m1; ++i) {
+            const int r = e * nloc + lidx(i, j, m);
+            const size_t gid = (size_t)(k * El[e][0] + i) + (size_t)npts * ((k * El[e][1] + j) + (size_t)npts * (k * El[e][2] + m));
+            sf.push_back({r, (int)gid, 1.0});
+            if (dmap[gid] >= 0) sd.push_back({r, dmap[gid], 1.0});
+          }
+    Csr F = from_triplets(nel * nloc, (int)ntot, sf), D = from_triplets(nel * nloc, md, sd);
+    for (int kk = l; kk < L - 1; ++kk) {
+      F = spgemm(g.refine[kk], F, true);
+      D = spgemm(g.refine[kk], D, true);
+    }
+    full.push_back(std::move(F));
+    dir.push_back(std::move(D));
+  }
+  return g;
+}
+
 }  // namespace mgb

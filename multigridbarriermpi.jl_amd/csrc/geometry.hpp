@@ -31,4 +31,8 @@ GeometryHost fem1d_native(int L);
 // triangles (docs/src/guide.md:317) or nullptr for the default [-1,1]^2.
 GeometryHost fem2d_native(int L, const double* K, int nK_rows);
 
+// Broken Q_k hexahedra ((k+1)^3 nodes per element, k = 1..3) on [-1,1]^3, octree refinement,
+// n = 8^(L-1) (k+1)^3 (reference: fem3d, src/MultiGridBarrierMPI.jl:698; k = 3 default src:682-684).
+GeometryHost fem3d_native(int L, int k);
+
 }  // namespace mgb

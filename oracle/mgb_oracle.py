@@ -265,6 +265,115 @@ def fem2d(L: int = 2, K: Optional[np.ndarray] = None) -> Geometry:
                     dict(full=full, dirichlet=dirichlet), dict(id=ident, dx=dx, dy=dy), refine, coarsen)
 
 
+def _lagrange_1d(k):
+    """Equispaced nodes on [0,1], values/derivative matrices of the Lagrange basis, Newton-Cotes weights."""
+    xi = np.linspace(0.0, 1.0, k + 1)
+    V = np.vander(xi, k + 1, increasing=True)
+    C = np.linalg.inv(V)                                   # monomial coefficients of the nodal basis
+
+    def basis(pts):
+        return np.vander(np.asarray(pts, dtype=np.float64), k + 1, increasing=True) @ C
+
+    def dbasis(pts):
+        pts = np.asarray(pts, dtype=np.float64)
+        dV = np.zeros((pts.size, k + 1))
+        for m in range(1, k + 1):
+            dV[:, m] = m * pts ** (m - 1)
+        return dV @ C
+
+    wq = {1: [1 / 2, 1 / 2], 2: [1 / 6, 4 / 6, 1 / 6], 3: [1 / 8, 3 / 8, 3 / 8, 1 / 8]}[k]
+    return xi, basis, dbasis, np.array(wq)
+
+
+def fem3d(L: int = 2, k: int = 3) -> Geometry:
+    """3-D broken Q_k hexahedra ((k+1)^3 nodes per element, k = 1..3) on [-1,1]^3, octree refinement:
+    8^(l-1) elements at level l (reference: fem3d_mpi, src:696-702, "Q_k", k=3 default src:682-684).
+    Equispaced tensor nodes (x fastest), Newton-Cotes tensor quadrature at the nodes, children of an element
+    in the order (cx + 2 cy + 4 cz)."""
+    if k not in (1, 2, 3):
+        raise ValueError("fem3d: k must be 1, 2 or 3")
+    xi, basis, dbasis, wq = _lagrange_1d(k)
+    m1 = k + 1
+    nloc = m1 ** 3
+
+    def elements(l):
+        """(ne, 3) integer lower corners in units of the level-l cell, in refinement order."""
+        E = np.zeros((1, 3), dtype=np.int64)
+        for _ in range(1, l):
+            off = np.array([[cx, cy, cz] for cz in (0, 1) for cy in (0, 1) for cx in (0, 1)], dtype=np.int64)
+            E = (2 * E[:, None, :] + off[None, :, :]).reshape(-1, 3)
+        return E
+
+    loc = np.array([[i, j, m] for m in range(m1) for j in range(m1) for i in range(m1)], dtype=np.int64)
+    E = elements(L)
+    ne = E.shape[0]
+    ncell = 2 ** (L - 1)
+    h = 2.0 / ncell
+    x = (-1.0 + h * (E[:, None, :] + xi[loc][None, :, :])).reshape(-1, 3)
+    w3 = (wq[loc[:, 0]] * wq[loc[:, 1]] * wq[loc[:, 2]]) * h ** 3
+    w = np.tile(w3, ne)
+    n = ne * nloc
+    B, dB = basis(xi), dbasis(xi) / h * 1.0                  # d/dx = (1/h) d/dxi
+    I1 = np.eye(m1)
+    Dx = np.kron(I1, np.kron(I1, dB))                          # x fastest
+    Dy = np.kron(I1, np.kron(dB, I1))
+    Dz = np.kron(dB, np.kron(I1, I1))
+    for M_ in (Dx, Dy, Dz):
+        M_[np.abs(M_) < 1e-13 / h] = 0.0
+    ops = {"id": sp.identity(n, format="csr")}
+    for key, blk in (("dx", Dx), ("dy", Dy), ("dz", Dz)):
+        ops[key] = _bdiag(np.broadcast_to(blk, (ne, nloc, nloc)))
+    # refine: parent nodal values -> the 8 children's nodal values
+    P1 = [basis(xi / 2), basis(0.5 + xi / 2)]                 # child 0 / 1 along one axis
+    blocks = []
+    for cz in (0, 1):
+        for cy in (0, 1):
+            for cx in (0, 1):
+                blocks.append(np.kron(P1[cz], np.kron(P1[cy], P1[cx])))
+    Pblk = np.vstack(blocks)
+    Pblk[np.abs(Pblk) < 1e-14] = 0.0
+    # coarsen by injection: parent node (i,j,m) sits at child node (2i mod k ...) of the child containing it
+    inj = np.zeros((nloc, 8 * nloc))
+    for r, (i, j, m) in enumerate(loc):
+        c, q = [], []
+        for a in (i, j, m):
+            t2 = 2 * a                                        # position in units of h_child/k
+            ca = 1 if t2 > k else 0                           # ties (t2 == k) go to child 0
+            c.append(ca)
+            q.append(t2 - ca * k)
+        child = c[0] + 2 * c[1] + 4 * c[2]
+        inj[r, child * nloc + q[0] + m1 * (q[1] + m1 * q[2])] = 1.0
+    refine, coarsen = [], []
+    for l in range(1, L):
+        nel = 8 ** (l - 1)
+        refine.append(_bdiag(np.broadcast_to(Pblk, (nel, 8 * nloc, nloc))))
+        coarsen.append(_bdiag(np.broadcast_to(inj, (nel, nloc, 8 * nloc))))
+    refine.append(sp.identity(n, format="csr"))
+    coarsen.append(sp.identity(n, format="csr"))
+    full, dirichlet = [], []
+    for l in range(1, L + 1):
+        El = elements(l)
+        nc = 2 ** (l - 1)
+        G = k * El[:, None, :] + loc[None, :, :]              # global tensor-grid index of every broken node
+        G = G.reshape(-1, 3)
+        npts = k * nc + 1
+        gid = G[:, 0] + npts * (G[:, 1] + npts * G[:, 2])
+        nl = gid.size
+        S = sp.csr_matrix((np.ones(nl), (np.arange(nl), gid)), shape=(nl, npts ** 3))
+        interior = np.all((G > 0) & (G < npts - 1), axis=1)
+        keep = np.zeros(npts ** 3, dtype=bool)
+        keep[gid[interior]] = True
+        Pm = S
+        for kk in range(l - 1, L - 1):
+            Pm = refine[kk] @ Pm
+        Pm = sp.csr_matrix(Pm)
+        Pm.eliminate_zeros()
+        full.append(Pm)
+        dirichlet.append(sp.csr_matrix(Pm[:, np.nonzero(keep)[0]]))
+    return Geometry(dict(kind="fem3d", L=L, dim=3, block=nloc, k=k), x, w,
+                    dict(full=full, dirichlet=dirichlet), ops, refine, coarsen)
+
+
 def _bdiag(blocks):
     """Block-diagonal CSR from an (ne, r, c) array of dense blocks."""
     blocks = np.asarray(blocks)
@@ -294,9 +403,12 @@ class AMG:
 
 DEFAULT_STATE = (("u", "dirichlet"), ("s", "full"))
 DEFAULT_D = {1: (("u", "id"), ("u", "dx"), ("s", "id")),
-             2: (("u", "id"), ("u", "dx"), ("u", "dy"), ("s", "id"))}
-DEFAULT_F = {1: lambda x: np.array([0.5, 0.0, 1.0]), 2: lambda x: np.array([0.5, 0.0, 0.0, 1.0])}
-DEFAULT_G = {1: lambda x: np.array([x[0], 2.0]), 2: lambda x: np.array([x[0] ** 2 + x[1] ** 2, 100.0])}
+             2: (("u", "id"), ("u", "dx"), ("u", "dy"), ("s", "id")),
+             3: (("u", "id"), ("u", "dx"), ("u", "dy"), ("u", "dz"), ("s", "id"))}   # src:736
+DEFAULT_F = {1: lambda x: np.array([0.5, 0.0, 1.0]), 2: lambda x: np.array([0.5, 0.0, 0.0, 1.0]),
+             3: lambda x: np.array([0.5, 0.0, 0.0, 0.0, 1.0])}                                  # src:737
+DEFAULT_G = {1: lambda x: np.array([x[0], 2.0]), 2: lambda x: np.array([x[0] ** 2 + x[1] ** 2, 100.0]),
+             3: lambda x: np.array([x[0] ** 2 + x[1] ** 2 + x[2] ** 2, 100.0])}                 # src:738
 
 
 def amg(geometry: Geometry, state_variables=DEFAULT_STATE, D=None) -> AMG:
@@ -650,6 +762,10 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
 
 def fem1d_solve(L=4, **kw):
     return amgb(fem1d(L), **kw)
+
+
+def fem3d_solve(L=2, k=3, **kw):
+    return amgb(fem3d(L, k), **kw)
 
 
 def fem2d_solve(L=2, K=None, **kw):

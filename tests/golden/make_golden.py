@@ -11,12 +11,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
 import mgb_oracle as O  # noqa: E402
 
-CASES = [("fem1d", 3, 1.0), ("fem1d", 4, 2.0), ("fem2d", 2, 1.5), ("fem2d", 3, 1.0), ("fem2d", 3, 2.0)]
+CASES = [("fem1d", 3, 1.0), ("fem1d", 4, 2.0), ("fem2d", 2, 1.5), ("fem2d", 3, 1.0), ("fem2d", 3, 2.0),
+         ("fem3d", 2, 1.0), ("fem3d", 2, 2.0)]          # fem3d: k = 3 (reference default)
 
 
 def main():
     for kind, L, p in CASES:
-        g = getattr(O, kind)(L)
+        g = getattr(O, kind)(L)                       # fem3d: default k = 3
         dim = g.discretization["dim"]
         sol = O.amgb(g, p=p)
         M = O.amg(g)

@@ -156,7 +156,7 @@ def _match_columns(Ro, Rg):
 
 
 @pytest.mark.parametrize("kind,L,p", [("fem1d", 3, 1.0), ("fem1d", 5, 1.5), ("fem2d", 2, 1.0), ("fem2d", 3, 1.5),
-                                      ("fem2d", 3, 2.0), ("fem2d", 2, 3.0), ("fem2d", 4, 1.0)])
+                                      ("fem2d", 3, 2.0), ("fem2d", 2, 3.0), ("fem2d", 4, 1.0), ("fem3d", 2, 1.5)])
 def test_barrier_kernels_match_oracle_all_levels(M, kind, L, p):
     A, Mo, B, z0, c, go = _problem(M, kind, L, p)
     rng = np.random.default_rng(11)
@@ -232,7 +232,8 @@ def test_fraction_to_boundary_trial_matches_oracle(M):
 
 
 # ---------------------------------------------------------------- whole solves
-CASES = [("fem1d", 3, 1.0), ("fem1d", 4, 2.0), ("fem2d", 2, 1.5), ("fem2d", 3, 1.0), ("fem2d", 3, 2.0)]
+CASES = [("fem1d", 3, 1.0), ("fem1d", 4, 2.0), ("fem2d", 2, 1.5), ("fem2d", 3, 1.0), ("fem2d", 3, 2.0),
+         ("fem3d", 2, 1.0), ("fem3d", 2, 2.0)]
 
 
 @pytest.mark.parametrize("kind,L,p", CASES)
@@ -302,7 +303,7 @@ def test_host_and_device_solver_paths_agree(M):
     assert rel(zg, zh) < ZTOL
 
 
-@pytest.mark.parametrize("kind,L,p", [("fem2d", 5, 1.5), ("fem1d", 10, 1.0)])
+@pytest.mark.parametrize("kind,L,p", [("fem2d", 5, 1.5), ("fem1d", 10, 1.0), ("fem3d", 3, 1.0)])
 def test_solve_properties_at_scale(M, kind, L, p):
     """Size-independent properties where a live oracle run would be slow (BASELINE configs[1])."""
     sol = getattr(M, kind + "_mpi_solve")(L=L, p=p)
@@ -315,7 +316,7 @@ def test_solve_properties_at_scale(M, kind, L, p):
     bnd = np.asarray((full @ np.ones(full.shape[1])) - (dirichlet @ np.ones(dirichlet.shape[1]))).ravel() > 0.5
     u0 = np.array([gfun(xi)[0] for xi in x])
     assert np.abs(z[bnd, 0] - u0[bnd]).max() < 1e-13                      # Dirichlet data untouched
-    grad2 = sum((g.operators[k] @ z[:, 0]) ** 2 for k in ("dx", "dy")[:dim])
+    grad2 = sum((g.operators[k] @ z[:, 0]) ** 2 for k in ("dx", "dy", "dz")[:dim])
     assert np.all(z[:, 1] > grad2 ** (p / 2))                               # strictly inside the cone
     cd = sol.SOL_main["c_dot_Dz"]
     assert np.all(np.diff(cd) <= 1e-9 * abs(cd[0]))                         # objective decreases along the path

@@ -192,3 +192,43 @@ def test_multifrontal_cholesky_selftest(lib):
     for nx, ny in ((1, 1), (3, 2), (17, 9), (120, 75)):
         assert lib.mgb_chol_selftest(nx, ny, C.byref(r), C.byref(f), C.byref(s)) == 0, lib.mgb_last_error()
         assert r.value < 1e-12
+
+
+@pytest.mark.parametrize("L,k", [(1, 1), (2, 1), (2, 2), (2, 3), (3, 2)])
+def test_native_fem3d_matches_oracle(L, k):
+    import mgb_amd
+    g, o = mgb_amd.fem3d(L, k), O.fem3d(L, k)
+    assert g.x.shape == (8 ** (L - 1) * (k + 1) ** 3, 3)
+    assert np.abs(g.x - o.x).max() < 1e-15 and np.abs(g.w - o.w).max() < 1e-16
+    assert set(g.operators) == {"id", "dx", "dy", "dz"}            # :dz in 3-D, src:736
+    for key in ("dx", "dy", "dz"):
+        assert abs(g.operators[key] - o.operators[key]).max() < 1e-12
+    for l in range(L):
+        assert abs(g.refine[l] - o.refine[l]).max() < 1e-13
+        assert abs(g.coarsen[l] - o.coarsen[l]).max() == 0
+        for key in ("full", "dirichlet"):
+            a, b = g.subspaces[key][l], o.subspaces[key][l]
+            assert a.shape == b.shape
+            assert (a.nnz == 0 and b.nnz == 0) or abs(a - b).max() < 1e-13
+
+
+def test_hessian_plan_fem3d_k5_barrier():
+    """K=5 (u id, dx, dy, dz; s id), 3 gradient components + slack: 10 Hessian slots (src:736)."""
+    g = O.fem3d(2, 2)
+    n = g.x.shape[0]
+    M = O.amg(g)
+    idx = [1, 2, 3, 4]
+    for level in (0, 1):
+        N, evaluate, destroy = _plan(g, O.DEFAULT_STATE, O.DEFAULT_D[3], idx, level)
+        rng = np.random.default_rng(4)
+        A = rng.normal(size=(n, 5, 5))
+        y = np.einsum("nij,nkj->nik", A, A)
+        y[:, 0, :] = 0
+        y[:, :, 0] = 0
+        slots = [(a, b) for a in range(4) for b in range(a, 4)]
+        Y = np.stack([g.w * y[:, idx[a], idx[b]] for a, b in slots], axis=1)
+        got = evaluate(Y)
+        want = O.hessian_recipe(M.D, g.w, y, M.R[level]).toarray()
+        destroy()
+        assert N == M.R[level].shape[1]
+        assert np.abs(got - want).max() < 1e-12 * max(1.0, np.abs(want).max())

@@ -192,3 +192,35 @@ def test_fem2d_solution_independent_of_linesearch_path():
     finally:
         O.BETA = old
     assert np.linalg.norm(a - b) / np.linalg.norm(a) < 1e-10
+
+
+@pytest.mark.parametrize("L,k", [(1, 3), (2, 1), (2, 3)])
+def test_structure_fem3d(L, k):
+    """fem3d: Q_k hexahedra, (k+1)^3 nodes per element (src:682-684), operator keys incl. :dz (src:736)."""
+    g = O.fem3d(L, k)
+    n = 8 ** (L - 1) * (k + 1) ** 3
+    assert g.x.shape == (n, 3) and abs(g.w.sum() - 8.0) < 1e-12 and g.w.min() > 0
+    assert set(g.operators) == {"id", "dx", "dy", "dz"}
+    x, y, z = g.x.T
+    deg = min(k, 2)
+    f = x ** deg * y + y * z
+    assert np.abs(g.operators["dx"] @ f - deg * x ** (deg - 1) * y).max() < 1e-11
+    assert np.abs(g.operators["dy"] @ f - (x ** deg + z)).max() < 1e-11
+    assert np.abs(g.operators["dz"] @ f - y).max() < 1e-11
+    for l in range(L):
+        assert abs(g.coarsen[l] @ g.refine[l] - sp.identity(g.refine[l].shape[1])).max() < 1e-12
+    npts = k * 2 ** (L - 1) + 1
+    assert g.subspaces["full"][-1].shape == (n, npts ** 3)
+    assert g.subspaces["dirichlet"][-1].shape == (n, (npts - 2) ** 3)
+
+
+def test_fem3d_solve_properties():
+    """src:735-745 defaults: D = [u id; u dx; u dy; u dz; s id], f = (.5,0,0,0,1), g = (|x|^2, 100)."""
+    sol = O.fem3d_solve(L=2, k=2, p=1.5)
+    z, g = sol.z, sol.geometry
+    assert z.shape == (216, 2)
+    grad2 = sum((g.operators[k] @ z[:, 0]) ** 2 for k in ("dx", "dy", "dz"))
+    assert np.all(z[:, 1] > grad2 ** 0.75)
+    bnd = np.any(np.abs(np.abs(g.x) - 1.0) < 1e-14, axis=1)
+    assert np.abs(z[bnd, 0] - np.sum(g.x[bnd] ** 2, axis=1)).max() < 1e-13
+    assert np.all(np.diff(sol.SOL_main["c_dot_Dz"]) < 1e-9)
