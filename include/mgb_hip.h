@@ -87,6 +87,12 @@ int mgb_all_isfinite(mgb_vec x, int* out);                    /* amgb_all_isfini
  * Uploads the geometry to HBM (the native_to_mpi step, src:259-338); levels are built on first use. */
 int mgb_amg_create(mgb_ctx ctx, mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D,
                    int nq, const int* idx_q, int idx_s, double p, mgb_amg* out);
+/* Barrier of an intersection of 1 or 2 power cones (upstream `intersect` of convex_Euclidian_power sets, as
+ * used by parabolic_solve: s1 >= u^2 and s2 >= |grad u|^p).  nq[c], idx_q[3*c + i], idx_s[c], p[c] per cone;
+ * idx_s2 (nullable) names an extra D row added to the cone's slack (feasibility phase), -1 for none. */
+int mgb_amg_create_cones(mgb_ctx ctx, mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D,
+                         int ncones, const int* nq, const int* idx_q, const int* idx_s, const int* idx_s2,
+                         const double* p, mgb_amg* out);
 int mgb_amg_destroy(mgb_amg a);
 int mgb_amg_dims(mgb_amg a, int* n, int* S, int* K, int* L, int* nY);
 int mgb_amg_level_size(mgb_amg a, int level, int* N, int* nnz_lower);

@@ -32,7 +32,7 @@ import ctypes as C
 
 __all__ = [
     "fem1d", "fem2d", "fem3d", "fem1d_mpi", "fem2d_mpi", "fem3d_mpi", "fem1d_mpi_solve", "fem2d_mpi_solve",
-    "fem3d_mpi_solve", "native_to_mpi",
+    "fem3d_mpi_solve", "parabolic_solve", "ParabolicSOL", "native_to_mpi",
     "mpi_to_native", "amgb", "Geometry", "AMGBSOL", "HPCVector", "HPCMatrix", "HPCSparseMatrix",
     "backend_hip", "amgb_zeros", "amgb_all_isfinite", "amgb_diag", "amgb_blockdiag", "map_rows", "map_rows_gpu",
     "_raw_array", "_to_cpu_array", "MGBError", "device_count", "AMG", "amg",
@@ -425,21 +425,32 @@ DEFAULT_G = {1: lambda x: np.array([x[0], 2.0]), 2: lambda x: np.array([x[0] ** 
 class AMG:
     """AMG hierarchy + barrier problem resident in HBM (upstream `amg` + `barrier`)."""
 
-    def __init__(self, geometry: Geometry, state_variables=DEFAULT_STATE, D=None, p: float = 1.0, idx=None):
+    def __init__(self, geometry: Geometry, state_variables=DEFAULT_STATE, D=None, p: float = 1.0, idx=None,
+                 cones=None):
+        """`cones` = [(idx, p) | (idx, p, idx_s2), ...] selects an intersection of up to two power cones
+        (idx = D rows of (q_1..q_d, s)); default: one cone on the last dim+1 rows of D with exponent p."""
         if geometry._geo is None:
             raise TypeError("AMG needs an MPI geometry (use native_to_mpi / fem*d_mpi)")
         dim = geometry.discretization["dim"]
         D = DEFAULT_D[dim] if D is None else D
         K = len(D)
-        if idx is None:
-            idx = list(range(K - dim - 1, K))       # convex_Euclidian_power(idx=2:dim+2)
+        if cones is None:
+            if idx is None:
+                idx = list(range(K - dim - 1, K))       # convex_Euclidian_power(idx=2:dim+2)
+            cones = [(list(idx), float(p))]
         self.geometry = geometry
-        self.state_variables, self.D, self.p, self.idx = tuple(state_variables), tuple(D), float(p), list(idx)
+        self.state_variables, self.D, self.p, self.cones = tuple(state_variables), tuple(D), float(p), list(cones)
+        self.idx = list(cones[0][0])
         backend = geometry.x.backend
-        iq = (C.c_int * (len(idx) - 1))(*idx[:-1])
+        nc = len(cones)
+        nq = (C.c_int * nc)(*[len(c[0]) - 1 for c in cones])
+        iq = (C.c_int * (3 * nc))(*sum([(list(c[0][:-1]) + [0, 0, 0])[:3] for c in cones], []))
+        isl = (C.c_int * nc)(*[int(c[0][-1]) for c in cones])
+        is2 = (C.c_int * nc)(*[int(c[2]) if len(c) > 2 else -1 for c in cones])
+        pp = (C.c_double * nc)(*[float(c[1]) for c in cones])
         h = C.c_void_p()
-        call("mgb_amg_create", backend.handle, geometry._geo, len(state_variables), _lib.str_array(state_variables),
-             K, _lib.str_array(D), len(idx) - 1, iq, int(idx[-1]), float(p), C.byref(h))
+        call("mgb_amg_create_cones", backend.handle, geometry._geo, len(state_variables),
+             _lib.str_array(state_variables), K, _lib.str_array(D), nc, nq, iq, isl, is2, pp, C.byref(h))
         self.handle = h
         n, S, K_, L, nY = (C.c_int() for _ in range(5))
         call("mgb_amg_dims", h, C.byref(n), C.byref(S), C.byref(K_), C.byref(L), C.byref(nY))
@@ -620,8 +631,61 @@ def fem2d_mpi_solve(L: int = 2, K=None, **kwargs) -> AMGBSOL:
     return amgb(fem2d_mpi(L, K, **geo_kw), **{k: v for k, v in kwargs.items() if k not in geo_kw})
 
 
+@dataclass
+class ParabolicSOL:
+    """src:512-516 field order: geometry, ts, u (one n x S snapshot per time step)."""
+    geometry: Geometry
+    ts: np.ndarray
+    u: list
+
+
+def parabolic_solve(geometry: Geometry, h=0.2, t0=0.0, t1=1.0, p=1.0, f1=None, g=None, tol=None, verbose=False,
+                    schedule="fine", solver="gpu", **rest) -> ParabolicSOL:
+    """MultiGridBarrier.parabolic_solve on an MPI geometry (imported at src:22,54; kwargs h, t1, p, verbose as in
+    test/test_parabolic.jl:48 and docs/src/guide.md:367,377).  Implicit Euler for
+        u_t - div(|grad u|^(p-2) grad u) = -f1 ;
+    each step minimises int (1/2h)(s1 - 2 u u_k) + (1/p) s2 + f1 u subject to s1 >= u^2, s2 >= |grad u|^p with the
+    barrier of the two-cone intersection (one GPU barrier solve per step; the time loop is host control flow).
+    Dirichlet data = boundary trace of the initial condition g (time independent)."""
+    if geometry._geo is None:
+        raise TypeError("parabolic_solve: geometry must come from native_to_mpi / fem*d_mpi")
+    dim = geometry.discretization["dim"]
+    g = DEFAULT_G[dim] if g is None else g
+    f1 = (lambda x: 0.5) if f1 is None else f1
+    ops = ("dx", "dy", "dz")[:dim]
+    state = (("u", "dirichlet"), ("s1", "full"), ("s2", "full"))
+    D = (("u", "id"),) + tuple(("u", o) for o in ops) + (("s1", "id"), ("s2", "id"))
+    K = dim + 3
+    cones = [([0, K - 2], 2.0), (list(range(1, dim + 1)) + [K - 1], float(p))]
+    M = AMG(geometry, state, D, p, cones=cones)
+    x = geometry.x.to_numpy()
+    n = x.shape[0]
+    u0 = np.array([np.asarray(g(xi), dtype=np.float64).reshape(-1)[0] for xi in x])
+    grad2 = sum((geometry.operators[o].host @ u0) ** 2 for o in ops)
+    z = np.concatenate([u0, np.full(n, 1.0 + float(np.max(u0 * u0))),
+                        np.full(n, 1.0 + float(np.max(grad2 ** (p / 2.0))))])
+    fgrid = np.array([float(f1(xi)) for xi in x])
+    nsteps = int(round((t1 - t0) / h))
+    ts = t0 + h * np.arange(nsteps + 1)
+    backend = geometry.x.backend
+    u = [HPCMatrix(z.reshape(n, 3, order="F"), backend)]
+    M.set_z(z)
+    for _ in range(nsteps):
+        c = np.zeros((n, K))
+        c[:, 0] = fgrid - z[:n] / h
+        c[:, K - 2] = 1.0 / (2.0 * h)
+        c[:, K - 1] = 1.0 / p
+        M.set_c(c)
+        M.solve(tol=tol, verbose=int(bool(verbose)), schedule=schedule, solver=solver)
+        z = M.get_z()
+        u.append(HPCMatrix(z.reshape(n, 3, order="F"), backend))
+    return ParabolicSOL(geometry, ts, u)
+
+
 def mpi_to_native(obj):
     """src:355-517: gather device objects back to native numpy/scipy types."""
+    if isinstance(obj, ParabolicSOL):                                   # src:495-517
+        return ParabolicSOL(mpi_to_native(obj.geometry), obj.ts, [_to_cpu_array(uk) for uk in obj.u])
     if isinstance(obj, Geometry):
         conv = lambda m: m.to_scipy() if isinstance(m, HPCSparseMatrix) else m
         return Geometry(dict(obj.discretization), _to_cpu_array(obj.x), _to_cpu_array(obj.w),

@@ -54,6 +54,8 @@ PROTOTYPES = {
     "mgb_all_isfinite": [H, c_int_p],
     "mgb_amg_create": [H, H, C.c_int, c_str_arr, C.c_int, c_str_arr, C.c_int, c_int_p, C.c_int, C.c_double,
                        C.POINTER(H)],
+    "mgb_amg_create_cones": [H, H, C.c_int, c_str_arr, C.c_int, c_str_arr, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p,
+                             c_dbl_p, C.POINTER(H)],
     "mgb_amg_destroy": [H],
     "mgb_amg_dims": [H, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p],
     "mgb_amg_level_size": [H, C.c_int, c_int_p, c_int_p],

@@ -110,20 +110,19 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
         }
       }
   }
-  // Hessian plan: A = sum_q sum_{a<=b} Y[q,slot(a,b)] * (B_a[q,:]' B_b[q,:] + sym), lower triangle only
-  const int nact = P.nact(), nY = P.nY();
-  std::vector<int> act(nact);
-  for (int i = 0; i < P.nq; ++i) act[i] = P.iq[i];
-  act[P.nq] = P.is;
+  // Hessian plan: A = sum_q sum_cones sum_{a<=b} Y[q, base_c + slot(a,b)] * (B_a[q,:]' B_b[q,:] + sym), lower
+  // triangle only; a, b run over the cone's active D rows (ConeSpec::col)
+  const int nY = P.nY();
   struct RowU {
     std::vector<int> cols;
     std::vector<double> val;     // nact x ncols
     std::vector<char> present;   // nact x ncols
   };
-  auto gather = [&](int q, RowU& u) {
+  auto gather = [&](int q, const ConeSpec& S, RowU& u) {
+    const int nact = S.nact();
     u.cols.clear();
     for (int a = 0; a < nact; ++a) {
-      const int r = q * K + act[a];
+      const int r = q * K + S.col(a);
       for (int e = pl.B.rowptr[r]; e < pl.B.rowptr[r + 1]; ++e) u.cols.push_back(pl.B.colidx[e]);
     }
     std::sort(u.cols.begin(), u.cols.end());
@@ -132,10 +131,10 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
     u.val.assign((size_t)nact * nc, 0.0);
     u.present.assign((size_t)nact * nc, 0);
     for (int a = 0; a < nact; ++a) {
-      const int r = q * K + act[a];
+      const int r = q * K + S.col(a);
       for (int e = pl.B.rowptr[r]; e < pl.B.rowptr[r + 1]; ++e) {
         const int j = (int)(std::lower_bound(u.cols.begin(), u.cols.end(), pl.B.colidx[e]) - u.cols.begin());
-        u.val[(size_t)a * nc + j] = pl.B.vals[e];
+        u.val[(size_t)a * nc + j] += pl.B.vals[e];
         u.present[(size_t)a * nc + j] = 1;
       }
     }
@@ -149,15 +148,19 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
   keys.reserve((size_t)n * 40);
   RowU u;
   for (int q = 0; q < n; ++q) {
-    gather(q, u);
-    const int nc = (int)u.cols.size();
-    for (int i = 0; i < nc; ++i)
-      for (int j = 0; j <= i; ++j) {
-        bool any = false;
-        for (int a = 0; a < nact && !any; ++a)
-          for (int b = a; b < nact && !any; ++b) any = structural(u, nc, a, b, i, j);
-        if (any) keys.push_back(((unsigned long long)u.cols[i] << 32) | (unsigned)u.cols[j]);
-      }
+    for (int ci = 0; ci < P.ncones; ++ci) {
+      const ConeSpec& S = P.cone[ci];
+      const int nact = S.nact();
+      gather(q, S, u);
+      const int nc = (int)u.cols.size();
+      for (int i = 0; i < nc; ++i)
+        for (int j = 0; j <= i; ++j) {
+          bool any = false;
+          for (int a = 0; a < nact && !any; ++a)
+            for (int b = a; b < nact && !any; ++b) any = structural(u, nc, a, b, i, j);
+          if (any) keys.push_back(((unsigned long long)u.cols[i] << 32) | (unsigned)u.cols[j]);
+        }
+    }
     if (keys.size() > (size_t)64 << 20) {  // compact periodically
       std::sort(keys.begin(), keys.end());
       keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
@@ -174,11 +177,11 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
   }
   for (int r = 0; r < pl.N; ++r) pl.Apat.rowptr[r + 1] += pl.Apat.rowptr[r];
   auto entry = [&](int r, int c) {
-    const int* b = pl.Apat.colidx.data() + pl.Apat.rowptr[r];
-    const int* e = pl.Apat.colidx.data() + pl.Apat.rowptr[r + 1];
-    return (int)(std::lower_bound(b, e, c) - pl.Apat.colidx.data());
+    const int* b0 = pl.Apat.colidx.data() + pl.Apat.rowptr[r];
+    const int* e0 = pl.Apat.colidx.data() + pl.Apat.rowptr[r + 1];
+    return (int)(std::lower_bound(b0, e0, c) - pl.Apat.colidx.data());
   };
-  // pass B: count, pass C: fill (terms of one entry end up ordered by q, then slot)
+  // pass B: count, pass C: fill (terms of one entry end up ordered by q, cone, slot)
   const int nnzA = pl.Apat.nnz();
   pl.T = Csr(nnzA, n * nY);
   std::vector<long long> cnt(nnzA + 1, 0);
@@ -199,27 +202,33 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
       pos.assign(cnt.begin(), cnt.end() - 1);
     }
     for (int q = 0; q < n; ++q) {
-      gather(q, u);
-      const int nc = (int)u.cols.size();
-      for (int i = 0; i < nc; ++i)
-        for (int j = 0; j <= i; ++j) {
-          int e = -1;
-          int slot = 0;
-          for (int a = 0; a < nact; ++a)
-            for (int b = a; b < nact; ++b, ++slot) {
-              if (!structural(u, nc, a, b, i, j)) continue;
-              if (e < 0) e = entry(u.cols[i], u.cols[j]);
-              if (pass == 0) {
-                cnt[e]++;
-              } else {
-                double coef = u.val[(size_t)a * nc + i] * u.val[(size_t)b * nc + j];
-                if (a != b) coef += u.val[(size_t)b * nc + i] * u.val[(size_t)a * nc + j];
-                const long long p = pos[e]++;
-                pl.T.colidx[p] = q * nY + slot;
-                pl.T.vals[p] = coef;
+      int base = 0;
+      for (int ci = 0; ci < P.ncones; ++ci) {
+        const ConeSpec& S = P.cone[ci];
+        const int nact = S.nact();
+        gather(q, S, u);
+        const int nc = (int)u.cols.size();
+        for (int i = 0; i < nc; ++i)
+          for (int j = 0; j <= i; ++j) {
+            int e = -1;
+            int slot = base;
+            for (int a = 0; a < nact; ++a)
+              for (int b = a; b < nact; ++b, ++slot) {
+                if (!structural(u, nc, a, b, i, j)) continue;
+                if (e < 0) e = entry(u.cols[i], u.cols[j]);
+                if (pass == 0) {
+                  cnt[e]++;
+                } else {
+                  double coef = u.val[(size_t)a * nc + i] * u.val[(size_t)b * nc + j];
+                  if (a != b) coef += u.val[(size_t)b * nc + i] * u.val[(size_t)a * nc + j];
+                  const long long pp = pos[e]++;
+                  pl.T.colidx[pp] = q * nY + slot;
+                  pl.T.vals[pp] = coef;
+                }
               }
-            }
-        }
+          }
+        base += S.nY();
+      }
     }
   }
   return pl;
@@ -231,10 +240,13 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
     : ctx_(ctx), n_(g.n), S_((int)spec.state_variables.size()), P_(P), spec_(spec) {
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
   if (P.K != (int)spec.D.size()) throw std::runtime_error("amg: barrier K != number of D rows");
-  if (P.nq < 1 || P.nq > 3) throw std::runtime_error("amg: barrier supports 1..3 gradient components");
-  for (int i = 0; i < P.nq; ++i)
-    if (P.iq[i] < 0 || P.iq[i] >= P.K) throw std::runtime_error("amg: barrier index out of range");
-  if (P.is < 0 || P.is >= P.K) throw std::runtime_error("amg: barrier index out of range");
+  if (P.ncones < 1 || P.ncones > 2) throw std::runtime_error("amg: barrier supports 1 or 2 cones");
+  for (int ci = 0; ci < P.ncones; ++ci) {
+    const ConeSpec& S = P.cone[ci];
+    if (S.nq < 1 || S.nq > 3) throw std::runtime_error("amg: barrier supports 1..3 gradient components");
+    for (int a = 0; a < S.nact(); ++a)
+      if (S.col(a) < 0 || S.col(a) >= P.K) throw std::runtime_error("amg: barrier index out of range");
+  }
   if ((int)g.w.size() != n_ || (int)g.x.size() != n_ * g.dim) throw std::runtime_error("amg: geometry x/w size mismatch");
   Csr Dstack = build_dstack(g, spec);
   Dstack_.upload(Dstack);
@@ -249,9 +261,9 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
   Dz_.alloc((size_t)n_ * K);
   v_.alloc((size_t)n_ * K);
   Y_.alloc((size_t)n_ * nY);
-  phi_cur_.alloc(n_);
-  phi_trial_.alloc(n_);
-  phi_trial2_.alloc(n_);
+  phi_cur_.alloc((size_t)n_ * P.ncones);
+  phi_trial_.alloc((size_t)n_ * P.ncones);
+  phi_trial2_.alloc((size_t)n_ * P.ncones);
   h_flag_.alloc(4);
   partials_.alloc((size_t)2 * f0_blocks(n_) + 16);
   scal_.alloc(8);
@@ -490,10 +502,15 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
     double minphi = INFINITY;
     for (int q = 0; q < n_; ++q) {
       const double* d = hdz.data() + (size_t)q * P_.K;
-      double qq = 0;
-      for (int i = 0; i < P_.nq; ++i) qq += d[P_.iq[i]] * d[P_.iq[i]];
-      const double sv = d[P_.is];
-      const double phi = (sv > 0 ? std::pow(sv, P_.a) : -1.0) - qq;
+      double phi = INFINITY, sv = INFINITY;
+      for (int ci = 0; ci < P_.ncones; ++ci) {
+        const ConeSpec& S = P_.cone[ci];
+        double qq = 0;
+        for (int i = 0; i < S.nq; ++i) qq += d[S.iq[i]] * d[S.iq[i]];
+        const double sc = d[S.is] + (S.is2 >= 0 ? d[S.is2] : 0.0);
+        phi = std::min(phi, (sc > 0 ? std::pow(sc, S.a) : -1.0) - qq);
+        sv = std::min(sv, sc);
+      }
       if (!(phi > 0) || !(sv > 0)) bad++;
       if (!(phi >= minphi)) {
         minphi = phi;
@@ -636,8 +653,13 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   host_solve_ = opt.host_solve;
   std::vector<long long> its(L, 0);
   refresh_dz0();
-  if (!amgb_step(t, lam_tol, opt.max_newton, its, st, opt.verbose))
-    throw std::runtime_error("amgb: initial centering failed");
+  {
+    // initial centering: repeat from the improved iterate (oracle INITIAL_CENTERING_ATTEMPTS)
+    bool ok0 = false;
+    for (int attempt = 0; attempt < kInitialCenteringAttempts && !ok0; ++attempt)
+      ok0 = amgb_step(t, lam_tol, opt.max_newton, its, st, opt.verbose);
+    if (!ok0) throw std::runtime_error("amgb: initial centering failed");
+  }
   st.its.insert(st.its.end(), its.begin(), its.end());
   st.ts.push_back(t);
   st.c_dot_Dz.push_back(c_dot_dz());

@@ -116,6 +116,7 @@ enum KernelClass {
 
 constexpr double kFracToBoundary = 0.1;   // == oracle FRAC_TO_BOUNDARY
 constexpr double kKappaGrowFrac = 0.25;   // == oracle KAPPA_GROW_FRAC
+constexpr int kInitialCenteringAttempts = 8;   // == oracle INITIAL_CENTERING_ATTEMPTS
 
 struct SolveOptions {
   bool host_solve = false;              // true: factor/solve on the host (MfChol), false: on the GPU (GpuChol)

@@ -143,21 +143,37 @@ AmgSpec make_spec(int S, const char* const* sv, int K, const char* const* D) {
   return spec;
 }
 
-BarrierParams make_params(int K, int nq, const int* idx_q, int idx_s, double p) {
-  need(nq >= 1 && nq <= 3 && idx_q, "barrier: nq must be 1..3");
-  need(p >= 1.0 && std::isfinite(p), "barrier: p must be >= 1");
+BarrierParams make_params_cones(int K, int ncones, const int* nq, const int* idx_q, const int* idx_s,
+                                const int* idx_s2, const double* p) {
+  need(ncones >= 1 && ncones <= 2 && nq && idx_q && idx_s && p, "barrier: 1 or 2 cones expected");
   BarrierParams P;
   P.K = K;
-  P.nq = nq;
-  for (int i = 0; i < nq; ++i) {
-    need(idx_q[i] >= 0 && idx_q[i] < K, "barrier: idx_q out of range");
-    P.iq[i] = idx_q[i];
+  P.ncones = ncones;
+  for (int c = 0; c < ncones; ++c) {
+    ConeSpec& S = P.cone[c];
+    need(nq[c] >= 1 && nq[c] <= 3, "barrier: nq must be 1..3");
+    need(p[c] >= 1.0 && std::isfinite(p[c]), "barrier: p must be >= 1");
+    S.nq = nq[c];
+    for (int i = 0; i < nq[c]; ++i) {
+      need(idx_q[3 * c + i] >= 0 && idx_q[3 * c + i] < K, "barrier: idx_q out of range");
+      S.iq[i] = idx_q[3 * c + i];
+    }
+    need(idx_s[c] >= 0 && idx_s[c] < K, "barrier: idx_s out of range");
+    S.is = idx_s[c];
+    S.is2 = idx_s2 ? idx_s2[c] : -1;
+    need(S.is2 < K, "barrier: idx_s2 out of range");
+    if (S.is2 < 0) S.is2 = -1;
+    S.a = 2.0 / p[c];
+    S.mu = (p[c] == 2.0) ? 0.0 : (p[c] < 2.0 ? 1.0 : 2.0);
   }
-  need(idx_s >= 0 && idx_s < K, "barrier: idx_s out of range");
-  P.is = idx_s;
-  P.a = 2.0 / p;
-  P.mu = (p == 2.0) ? 0.0 : (p < 2.0 ? 1.0 : 2.0);
   return P;
+}
+
+BarrierParams make_params(int K, int nq, const int* idx_q, int idx_s, double p) {
+  need(nq >= 1 && nq <= 3 && idx_q, "barrier: nq must be 1..3");
+  int iq3[3] = {0, 0, 0};
+  for (int i = 0; i < nq; ++i) iq3[i] = idx_q[i];
+  return make_params_cones(K, 1, &nq, iq3, &idx_s, nullptr, &p);
 }
 
 }  // namespace
@@ -429,6 +445,25 @@ int mgb_amg_create(mgb_ctx ctx, mgb_geo g, int S, const char* const* state_vars,
     need(ctx && g && out, "null argument");
     AmgSpec spec = make_spec(S, state_vars, K, D);
     BarrierParams P = make_params(K, nq, idx_q, idx_s, p);
+    auto* a = new mgb_amg_s{ctx, nullptr, {}};
+    try {
+      const auto t0 = std::chrono::steady_clock::now();
+      a->amg.reset(new Amg(ctx->ctx, g->g, spec, P));
+      a->stats.t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } catch (...) {
+      delete a;
+      throw;
+    }
+    *out = a;
+  });
+}
+int mgb_amg_create_cones(mgb_ctx ctx, mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D,
+                         int ncones, const int* nq, const int* idx_q, const int* idx_s, const int* idx_s2,
+                         const double* p, mgb_amg* out) {
+  return guard([&] {
+    need(ctx && g && out, "null argument");
+    AmgSpec spec = make_spec(S, state_vars, K, D);
+    BarrierParams P = make_params_cones(K, ncones, nq, idx_q, idx_s, idx_s2, p);
     auto* a = new mgb_amg_s{ctx, nullptr, {}};
     try {
       const auto t0 = std::chrono::steady_clock::now();

@@ -97,7 +97,7 @@ __device__ inline double pow_a(double s, double a) {
   return pow(s, a);
 }
 
-__device__ inline Cone load_cone(const BarrierParams& P, const double* dz) {
+__device__ inline Cone load_cone(const ConeSpec& P, const double* dz) {
   Cone c;
   double qq = 0.0;
 #pragma unroll
@@ -105,7 +105,7 @@ __device__ inline Cone load_cone(const BarrierParams& P, const double* dz) {
     c.q[i] = (i < P.nq) ? dz[P.iq[i]] : 0.0;
     qq += c.q[i] * c.q[i];
   }
-  c.s = dz[P.is];
+  c.s = dz[P.is] + (P.is2 >= 0 ? dz[P.is2] : 0.0);
   c.ok = c.s > 0.0;
   c.sa = c.ok ? pow_a(c.s, P.a) : -1.0;
   c.phi = c.sa - qq;
@@ -113,8 +113,8 @@ __device__ inline Cone load_cone(const BarrierParams& P, const double* dz) {
   return c;
 }
 
-// phi_ref (nullable): cone distance of every row at the current iterate; a trial row with
-// phi < frac*phi_ref[q] is treated as infeasible (fraction-to-the-boundary rule of the line search).
+// phi_ref (nullable, n x ncones): cone distances of every row at the current iterate; a trial row with
+// phi < frac*phi_ref is treated as infeasible (fraction-to-the-boundary rule of the line search).
 __global__ __launch_bounds__(kBlock) void barrier_f0_kernel(int n, BarrierParams P, const double* __restrict__ Dz,
                                                              const double* __restrict__ w,
                                                              const double* __restrict__ c,
@@ -126,10 +126,13 @@ __global__ __launch_bounds__(kBlock) void barrier_f0_kernel(int n, BarrierParams
     const double* dz = Dz + q * P.K;
     const double* cq = c + q * P.K;
     const double wq = w[q];
-    Cone k = load_cone(P, dz);
-    if (phi_ref && !(k.phi >= frac * phi_ref[q])) k.ok = false;
-    if (phi_out) phi_out[q] = k.phi;
-    const double F = k.ok ? (-log(k.phi) - P.mu * log(k.s)) : INFINITY;
+    double F = 0.0;
+    for (int ci = 0; ci < P.ncones; ++ci) {
+      Cone k = load_cone(P.cone[ci], dz);
+      if (phi_ref && !(k.phi >= frac * phi_ref[q * P.ncones + ci])) k.ok = false;
+      if (phi_out) phi_out[q * P.ncones + ci] = k.phi;
+      F += k.ok ? (-log(k.phi) - P.cone[ci].mu * log(k.s)) : INFINITY;
+    }
     accF += wq * F;
     double lin = 0.0;
     for (int j = 0; j < P.K; ++j) lin += cq[j] * dz[j];
@@ -151,32 +154,45 @@ __global__ __launch_bounds__(kBlock) void barrier_f1_kernel(int n, BarrierParams
     const double* cq = c + q * P.K;
     double* vq = v + q * P.K;
     const double wq = w[q];
-    Cone k = load_cone(P, dz);
-    const double ds = P.a * pow_a(k.s, P.a - 1.0);  // d(s^a)/ds
     for (int j = 0; j < P.K; ++j) vq[j] = wq * (t * cq[j]);
-    for (int i = 0; i < P.nq; ++i) vq[P.iq[i]] = wq * (2.0 * k.q[i] / k.phi + t * cq[P.iq[i]]);
-    vq[P.is] = wq * (-ds / k.phi - P.mu / k.s + t * cq[P.is]);
+    for (int ci = 0; ci < P.ncones; ++ci) {
+      const ConeSpec& S = P.cone[ci];
+      Cone k = load_cone(S, dz);
+      const double ds = S.a * pow_a(k.s, S.a - 1.0);  // d(s^a)/ds
+      for (int i = 0; i < S.nq; ++i) vq[S.iq[i]] += wq * (2.0 * k.q[i] / k.phi);
+      const double gs = wq * (-ds / k.phi - S.mu / k.s);
+      vq[S.is] += gs;
+      if (S.is2 >= 0) vq[S.is2] += gs;
+    }
   }
 }
 
 __global__ __launch_bounds__(kBlock) void barrier_f2_kernel(int n, BarrierParams P, const double* __restrict__ Dz,
                                                              const double* __restrict__ w, double* Y) {
-  const int nact = P.nq + 1, nY = nact * (nact + 1) / 2;
+  const int nY = P.nY();
   for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < n; q += (long long)gridDim.x * kBlock) {
     const double* dz = Dz + q * P.K;
     double* yq = Y + q * nY;
     const double wq = w[q];
-    Cone k = load_cone(P, dz);
-    const double a = P.a;
-    const double ds = a * pow_a(k.s, a - 1.0);
-    const double dds = (a == 1.0) ? 0.0 : a * (a - 1.0) * pow_a(k.s, a - 2.0);
-    const double ip = 1.0 / k.phi, ip2 = ip * ip;
     int slot = 0;
-    for (int i = 0; i < P.nq; ++i) {
-      for (int j = i; j < P.nq; ++j) yq[slot++] = wq * (4.0 * k.q[i] * k.q[j] * ip2 + (i == j ? 2.0 * ip : 0.0));
-      yq[slot++] = wq * (-2.0 * k.q[i] * ds * ip2);
+    for (int ci = 0; ci < P.ncones; ++ci) {
+      const ConeSpec& S = P.cone[ci];
+      Cone k = load_cone(S, dz);
+      const double a = S.a;
+      const double ds = a * pow_a(k.s, a - 1.0);
+      const double dds = (a == 1.0) ? 0.0 : a * (a - 1.0) * pow_a(k.s, a - 2.0);
+      const double ip = 1.0 / k.phi, ip2 = ip * ip;
+      // Hessian over (q_0..q_{nq-1}, s); a second slack column repeats the s row/column
+      double h[4][4];
+      for (int i = 0; i < S.nq; ++i) {
+        for (int j = 0; j < S.nq; ++j) h[i][j] = 4.0 * k.q[i] * k.q[j] * ip2 + (i == j ? 2.0 * ip : 0.0);
+        h[i][S.nq] = h[S.nq][i] = -2.0 * k.q[i] * ds * ip2;
+      }
+      h[S.nq][S.nq] = -dds * ip + ds * ds * ip2 + S.mu / (k.s * k.s);
+      const int nact = S.nact();
+      for (int i = 0; i < nact; ++i)
+        for (int j = i; j < nact; ++j) yq[slot++] = wq * h[min(i, S.nq)][min(j, S.nq)];
     }
-    yq[slot] = wq * (-dds * ip + ds * ds * ip2 + P.mu / (k.s * k.s));
   }
 }
 

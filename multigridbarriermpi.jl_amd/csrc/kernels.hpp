@@ -14,17 +14,33 @@ struct DevCsr {
   double* vals = nullptr;
 };
 
-// Power-cone barrier  Q = {(q,s): s >= |q|^p}:  F = -log(s^(2/p) - |q|^2) - mu log s, acting on
-// columns iq[0..nq) and is of the n x K row-major matrix Dz.
-struct BarrierParams {
-  int K = 0;
+// One power cone  Q = {(q,s): s >= |q|^p}  with barrier  F = -log(s^(2/p) - |q|^2) - mu log s  acting on
+// columns iq[0..nq) and `is` of the n x K row-major matrix Dz.  If is2 >= 0 the slack is Dz[is] + Dz[is2]
+// (feasibility phase: the extra column relaxes the cone).
+struct ConeSpec {
   int nq = 0;
   int iq[3] = {0, 0, 0};
   int is = 0;
+  int is2 = -1;
   double a = 2.0;   // 2/p
   double mu = 1.0;
-  int nact() const { return nq + 1; }
-  int nY() const { return (nq + 1) * (nq + 2) / 2; }
+  __host__ __device__ int nact() const { return nq + 1 + (is2 >= 0 ? 1 : 0); }
+  __host__ __device__ int nY() const { return nact() * (nact() + 1) / 2; }
+  // active column a (0..nact) -> row of D
+  __host__ __device__ int col(int a) const { return a < nq ? iq[a] : (a == nq ? is : is2); }
+};
+
+// Barrier of an intersection of up to two power cones (upstream `convex_Euclidian_power` and its
+// intersection): F = sum of the cone barriers.  Hessian slots: cone 0's (a<=b) pairs, then cone 1's.
+struct BarrierParams {
+  int K = 0;
+  int ncones = 1;
+  ConeSpec cone[2];
+  __host__ __device__ int nY() const {
+    int s = 0;
+    for (int c = 0; c < ncones; ++c) s += cone[c].nY();
+    return s;
+  }
 };
 
 // y = (y0 ? y0 : 0) + A x      (y may alias y0)
@@ -34,14 +50,15 @@ void launch_waxpby(hipStream_t st, int n, const double* x, double alpha, const d
 // out2[0] = sum_q w F(Dz_q) ; out2[1] = sum_q w <c_q, Dz_q>   (+inf / NaN if any row infeasible)
 // partials: scratch of 2*f0_blocks(n) doubles.
 int f0_blocks(int n);
-// phi_ref (nullable) + frac: fraction-to-the-boundary test of a line-search trial; phi_out (nullable): per-row
-// cone distance s^(2/p) - |q|^2 of this evaluation.
+// phi_ref (nullable, n x ncones) + frac: fraction-to-the-boundary test of a line-search trial; phi_out
+// (nullable, n x ncones): per-row cone distances s^(2/p) - |q|^2 of this evaluation.
 void launch_barrier_f0(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
                        const double* phi_ref, double frac, double* phi_out, double* partials, double* out2);
 // v[q,k] = w_q (dF/dDz_k + t c[q,k])
 void launch_barrier_f1(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
                        double t, double* v);
-// Y[q,slot(a,b)] = w_q d2F/dDz_a dDz_b over the active columns (a<=b), slot = a*nact - a(a-1)/2 + (b-a)
+// Y[q, base_c + slot(a,b)] = w_q d2F/dDz_a dDz_b over cone c's active columns (a<=b),
+// slot = a*nact - a(a-1)/2 + (b-a)
 void launch_barrier_f2(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, double* Y);
 // out[0] = sum x_i y_i ; partials scratch of f0_blocks(n) doubles
 void launch_dot(hipStream_t st, int n, const double* x, const double* y, double* partials, double* out);

@@ -494,6 +494,25 @@ def convex_Euclidian_power(idx, p) -> PowerConeBarrier:
     return PowerConeBarrier(tuple(idx), float(p))
 
 
+@dataclass
+class ConeIntersection:
+    """Intersection of power cones acting on disjoint column sets of Dz (upstream `intersect` of
+    convex sets, used by parabolic_solve): the barrier is the sum of the cone barriers."""
+    cones: Sequence[PowerConeBarrier]
+
+    def phi(self, Y):
+        return np.stack([Q.phi(Y) for Q in self.cones], axis=1)
+
+    def F(self, x, Y):
+        return sum(Q.F(x, Y) for Q in self.cones)
+
+    def F1(self, x, Y):
+        return sum(Q.F1(x, Y) for Q in self.cones)
+
+    def F2(self, x, Y):
+        return sum(Q.F2(x, Y) for Q in self.cones)
+
+
 class Barrier:
     """upstream `barrier(F)` -> (f0, f1, f2); algebra pinned by
     test/test_apply_d.jl:44 (apply_D), test/test_column_extract.jl:50-80 (f1 pieces) and
@@ -570,6 +589,7 @@ def hessian_recipe(D, w, y, R=None):
 BETA = 0.5          # backtracking factor
 ARMIJO = 0.1        # sufficient-decrease constant
 MIN_STEP = 1e-8     # give up the line search below this step length
+INITIAL_CENTERING_ATTEMPTS = 8   # Newton budgets allowed for the first centering at t0
 KAPPA_GROW_FRAC = 0.25  # kappa grows back (kappa <- min(kappa0, kappa^2)) only after a centering with <= 25 % of max_newton
 REFINE = True       # after the first acceptable step keep halving while the objective improves
 FRAC_TO_BOUNDARY = 0.1  # a step may not shrink any row's cone distance phi below this fraction of its value
@@ -698,11 +718,18 @@ def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max
         return float(sum(np.dot(M.w * c[:, k], Dz[:, k]) for k in range(len(M.D))))
 
     Dz0 = B.apply_D(M.D, z)
-    SOL = amgb_step(B, M, z, Dz0, t * c, max_newton, lam_tol, log, schedule)
-    if not SOL["converged"]:
+    # initial centering: a far-away start (e.g. the previous time step of parabolic_solve, which sits next to
+    # the cone boundary) may need more than one Newton budget; keep centering from the improved iterate
+    it0 = np.zeros(len(M.R), dtype=np.int64)
+    for attempt in range(INITIAL_CENTERING_ATTEMPTS):
+        SOL = amgb_step(B, M, z, Dz0, t * c, max_newton, lam_tol, log, schedule)
+        it0 += SOL["its"]
+        z, Dz0 = SOL["z"], SOL["Dz0"]
+        if SOL["converged"]:
+            break
+    else:
         raise RuntimeError("amgb: initial centering failed at t=%g" % t)
-    z, Dz0 = SOL["z"], SOL["Dz0"]
-    its.append(SOL["its"]); ts.append(t); cdots.append(cdot(Dz0))
+    its.append(it0); ts.append(t); cdots.append(cdot(Dz0))
     k = 1
     while t <= 1 / tol and kappa > 1 and k < maxit:
         k += 1
@@ -758,6 +785,73 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
     SOL = amgb_core(B, M, zvec, c, tol, t=t, maxit=maxit, kappa=kappa, log=log, schedule=schedule)
     z = SOL.pop("z").reshape(z0.shape, order="F")
     return AMGBSOL(z, None, SOL, log or [], geometry)
+
+
+@dataclass
+class ParabolicSOL:
+    """src:512-516 field order: geometry, ts, u (one n x S snapshot per time)."""
+    geometry: Geometry
+    ts: np.ndarray
+    u: list
+
+
+def parabolic_problem(geometry, p):
+    """state variables, D and the cone intersection of the implicit-Euler step of the parabolic p-Laplace flow
+        u_t - div(|grad u|^(p-2) grad u) = -f1 :
+    minimise  int (1/2h)(s1 - 2 u u_k) + (1/p) s2 + f1 u   s.t.  s1 >= u^2,  s2 >= |grad u|^p."""
+    dim = geometry.discretization["dim"]
+    ops = ("dx", "dy", "dz")[:dim]
+    state = (("u", "dirichlet"), ("s1", "full"), ("s2", "full"))
+    D = (("u", "id"),) + tuple(("u", o) for o in ops) + (("s1", "id"), ("s2", "id"))
+    K = dim + 3
+    cones = [([0, K - 2], 2.0), (list(range(1, dim + 1)) + [K - 1], float(p))]
+    return state, D, K, cones, ops
+
+
+def parabolic_initial(geometry, p, g):
+    """z0 = [u0; s1; s2]: u0 = g(x)[0] at every node, constant slacks strictly inside both cones."""
+    dim = geometry.discretization["dim"]
+    ops = ("dx", "dy", "dz")[:dim]
+    x = geometry.x
+    u0 = np.array([g(xi)[0] for xi in x], dtype=np.float64)
+    grad2 = sum((geometry.operators[o] @ u0) ** 2 for o in ops)
+    n = x.shape[0]
+    s1 = np.full(n, 1.0 + float(np.max(u0 * u0)))
+    s2 = np.full(n, 1.0 + float(np.max(grad2 ** (p / 2.0))))
+    return np.concatenate([u0, s1, s2])
+
+
+def parabolic_cost(n, K, p, h, fgrid, uk):
+    c = np.zeros((n, K))
+    c[:, 0] = fgrid - uk / h
+    c[:, K - 2] = 1.0 / (2.0 * h)
+    c[:, K - 1] = 1.0 / p
+    return c
+
+
+def parabolic_solve(geometry: Geometry, h=0.2, t0=0.0, t1=1.0, p=1.0, f1=None, g=None, tol=None, verbose=False,
+                    schedule=None) -> ParabolicSOL:
+    """upstream `parabolic_solve(geometry; h, t1, p, ...)` (kwargs evidenced at test/test_parabolic.jl:48,
+    docs/src/guide.md:367,377): implicit Euler, one barrier solve (amgb main phase) per time step; the
+    Dirichlet data is the (time-independent) boundary trace of the initial condition g."""
+    dim = geometry.discretization["dim"]
+    g = DEFAULT_G[dim] if g is None else g
+    f1 = (lambda x: 0.5) if f1 is None else f1
+    tol = math.sqrt(np.finfo(np.float64).eps) if tol is None else tol
+    state, D, K, cones, ops = parabolic_problem(geometry, p)
+    M = amg(geometry, state, D)
+    B = Barrier(ConeIntersection([convex_Euclidian_power(idx, pp) for idx, pp in cones]))
+    n = M.x.shape[0]
+    z = parabolic_initial(geometry, p, g)
+    fgrid = np.array([f1(xi) for xi in M.x], dtype=np.float64)
+    nsteps = int(round((t1 - t0) / h))
+    ts = t0 + h * np.arange(nsteps + 1)
+    u = [z.reshape(n, 3, order="F").copy()]
+    for _ in range(nsteps):
+        c = parabolic_cost(n, K, p, h, fgrid, z[:n])
+        z = amgb_core(B, M, z, c, tol, schedule=schedule)["z"]
+        u.append(z.reshape(n, 3, order="F").copy())
+    return ParabolicSOL(geometry, ts, u)
 
 
 def fem1d_solve(L=4, **kw):
