@@ -602,14 +602,31 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
     c = np.vstack([np.asarray(f(xi), dtype=np.float64) for xi in x])         # f_grid (n, K)
     M.set_c(c)
     M.set_z(z0.reshape(-1, order="F"))
-    y0 = M.f0(M.L - 1, np.zeros(M.level_size(M.L - 1)[0]), 0.0)
+    Nf = M.level_size(M.L - 1)[0]
+    y0 = M.f0(M.L - 1, np.zeros(Nf), 0.0)
+    SOL_feasibility = None
     if not math.isfinite(y0):
-        raise NotImplementedError("amgb: the initial point is not strictly feasible; the feasibility phase "
-                                  "(SOL_feasibility) is not built yet (SURVEY §8f-3)")
+        # Feasibility phase (SOL_feasibility, src:428-455).  For the power-cone family it has a closed form:
+        # the slack row is `id` of a :full state variable (that space contains the constants), so a constant
+        # shift sigma = 1 + max(|q|^p - s) of that variable is strictly feasible.  Dz comes from the device.
+        idx = M.idx
+        var, op = M.D[idx[-1]]
+        names = [sv[0] for sv in M.state_variables]
+        if op != "id" or dict(M.state_variables)[var] != "full":
+            raise NotImplementedError("amgb: feasibility phase needs the cone's slack to be `id` of a :full variable")
+        Dz = M.apply_D(M.L - 1, np.zeros(Nf))
+        q2 = np.sum(Dz[:, idx[:-1]] ** 2, axis=1)
+        sigma = 1.0 + float(np.max(q2 ** (p / 2.0) - Dz[:, idx[-1]]))
+        z0[:, names.index(var)] += sigma
+        M.set_z(z0.reshape(-1, order="F"))
+        if not math.isfinite(M.f0(M.L - 1, np.zeros(Nf), 0.0)):
+            raise MGBError(-3, "amgb: feasibility phase failed")
+        SOL_feasibility = dict(shift=sigma, its=np.zeros((M.L, 0), dtype=np.int64), ts=np.zeros(0),
+                               c_dot_Dz=np.zeros(0), t_elapsed=0.0)
     SOL = M.solve(tol=tol, t=t, kappa=kappa, maxit=maxit, verbose=2 if verbose and verbose > 1 else int(bool(verbose)),
                   schedule=schedule, solver=solver)
     z = M.get_z().reshape(z0.shape, order="F")
-    return AMGBSOL(HPCMatrix(z, geometry.x.backend), None, SOL, [], geometry)
+    return AMGBSOL(HPCMatrix(z, geometry.x.backend), SOL_feasibility, SOL, [], geometry)
 
 
 def fem1d_mpi_solve(L: int = 4, **kwargs) -> AMGBSOL:

@@ -444,16 +444,23 @@ class PowerConeBarrier:
     default is ForwardDiff of F: identical up to rounding)."""
     idx: Sequence[int]
     p: float
+    idx_s2: int = -1     # feasibility phase: the cone's slack is Y[:, idx[-1]] + Y[:, idx_s2]
+
+    def _qs(self, Y):
+        s = Y[:, self.idx[-1]]
+        if self.idx_s2 >= 0:
+            s = s + Y[:, self.idx_s2]
+        return Y[:, list(self.idx[:-1])], s
 
     def phi(self, Y):
         """Distance function of the cone: phi = s^(2/p) - |q|^2 (negative when s <= 0)."""
-        q, s = Y[:, self.idx[:-1]], Y[:, self.idx[-1]]
+        q, s = self._qs(Y)
         a = 2.0 / self.p
         with np.errstate(all="ignore"):
             return np.where(s > 0, np.power(np.abs(s), a), -1.0) - np.sum(q * q, axis=1)
 
     def F(self, x, Y):
-        s = Y[:, self.idx[-1]]
+        s = self._qs(Y)[1]
         phi = self.phi(Y)
         with np.errstate(all="ignore"):
             val = -np.log(phi) - barrier_mu(self.p) * np.log(s)
@@ -462,20 +469,22 @@ class PowerConeBarrier:
 
     def F1(self, x, Y):
         n, K = Y.shape
-        q, s = Y[:, self.idx[:-1]], Y[:, self.idx[-1]]
+        q, s = self._qs(Y)
         a = 2.0 / self.p
         mu = barrier_mu(self.p)
         phi = np.power(s, a) - np.sum(q * q, axis=1)
         ds = a * np.power(s, a - 1)
         G = np.zeros((n, K))
-        G[:, self.idx[:-1]] = 2 * q / phi[:, None]
+        G[:, list(self.idx[:-1])] = 2 * q / phi[:, None]
         G[:, self.idx[-1]] = -ds / phi - mu / s
+        if self.idx_s2 >= 0:
+            G[:, self.idx_s2] = G[:, self.idx[-1]]
         return G
 
     def F2(self, x, Y):
         n, K = Y.shape
         qi, si = list(self.idx[:-1]), self.idx[-1]
-        q, s = Y[:, qi], Y[:, si]
+        q, s = self._qs(Y)
         a = 2.0 / self.p
         mu = barrier_mu(self.p)
         phi = np.power(s, a) - np.sum(q * q, axis=1)
@@ -487,6 +496,11 @@ class PowerConeBarrier:
                 H[:, ci, cj] = 4 * q[:, i] * q[:, j] / phi ** 2 + (2 / phi if i == j else 0.0)
             H[:, ci, si] = H[:, si, ci] = -2 * q[:, i] * ds / phi ** 2
         H[:, si, si] = -dds / phi + ds * ds / phi ** 2 + mu / (s * s)
+        if self.idx_s2 >= 0:          # the extra slack column repeats the s row/column
+            s2 = self.idx_s2
+            H[:, s2, :] = H[:, si, :]
+            H[:, :, s2] = H[:, :, si]
+            H[:, s2, s2] = H[:, si, si]
         return H
 
 
@@ -706,7 +720,9 @@ def amgb_step(B: Barrier, M: AMG, z, Dz0, c, maxit, lam_tol, log=None, schedule=
 
 
 def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max_newton=None, log=None,
-              schedule=None):
+              schedule=None, early_stop=None):
+    """`early_stop(Dz0) -> bool` is evaluated after every centering (feasibility phase: stop as soon as the
+    original cone is strictly satisfied)."""
     if max_newton is None:
         max_newton = int(math.ceil(math.log2(-math.log2(np.finfo(np.float64).eps)))) + 2 + 40
     lam_tol = math.sqrt(float(np.min(M.w))) / 2
@@ -731,7 +747,8 @@ def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max
         raise RuntimeError("amgb: initial centering failed at t=%g" % t)
     its.append(it0); ts.append(t); cdots.append(cdot(Dz0))
     k = 1
-    while t <= 1 / tol and kappa > 1 and k < maxit:
+    stopped = early_stop is not None and early_stop(Dz0)
+    while t <= 1 / tol and kappa > 1 and k < maxit and not stopped:
         k += 1
         it_k = np.zeros(len(M.R), dtype=np.int64)
         while kappa > 1:
@@ -747,7 +764,8 @@ def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max
             if kappa < 1 + 1e-3:
                 kappa = 1.0
         its.append(it_k); ts.append(t); cdots.append(cdot(Dz0))
-    if t <= 1 / tol:
+        stopped = early_stop is not None and early_stop(Dz0)
+    if t <= 1 / tol and not stopped:
         raise RuntimeError("amgb: convergence failure at t=%g kappa=%g" % (t, kappa))
     return dict(z=z, its=np.array(its).T, ts=np.array(ts), c_dot_Dz=np.array(cdots),
                 t_elapsed=time.time() - t_begin)
@@ -779,12 +797,35 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
     B = Barrier(Q)
     zvec = z0.reshape(-1, order="F")
     Dz = B.apply_D(M.D, zvec)
-    if not np.all(np.isfinite(Q.F(x, Dz))):
-        raise NotImplementedError("oracle: feasibility phase not restated (SURVEY §8f-3); start must be strictly feasible")
     log = [] if keep_log else None
+    SOL_feas = None
+    if not np.all(np.isfinite(Q.F(x, Dz))):
+        zvec, SOL_feas = amgb_phase1(geometry, state_variables, M.Dspec, Q, zvec, Dz, tol, schedule)
     SOL = amgb_core(B, M, zvec, c, tol, t=t, maxit=maxit, kappa=kappa, log=log, schedule=schedule)
     z = SOL.pop("z").reshape(z0.shape, order="F")
-    return AMGBSOL(z, None, SOL, log or [], geometry)
+    return AMGBSOL(z, SOL_feas, SOL, log or [], geometry)
+
+
+def amgb_phase1(geometry, state_variables, D, Q: PowerConeBarrier, zvec, Dz, tol, schedule=None):
+    """Feasibility phase (upstream amgb_phase1; SOL_feasibility of src:428-455).  For the power-cone family
+    the phase-1 problem "find z with Dz strictly inside Q" has a closed-form solution: the cone's slack row
+    is `id` applied to a state variable living in the :full subspace, which contains the constants, so
+    shifting that variable by sigma = 1 + max_rows(|q|^p - s) lands strictly inside the cone without
+    touching u (a relaxed-cone Newton phase would be singular along (ds, dsigma) = (d, -d)).  Other layouts
+    (slack in a space without constants, slack row not an identity) are rejected."""
+    n = geometry.x.shape[0]
+    var, op = D[Q.idx[-1]]
+    names = [sv[0] for sv in state_variables]
+    if op != "id" or dict(state_variables)[var] != "full":
+        raise NotImplementedError("feasibility phase: the cone's slack must be `id` of a :full state variable")
+    q, s = Q._qs(Dz)
+    sigma = 1.0 + float(np.max(np.sum(q * q, axis=1) ** (Q.p / 2.0) - s))
+    z = zvec.copy()
+    k = names.index(var)
+    z[k * n:(k + 1) * n] += sigma
+    L = len(geometry.refine)
+    SOL = dict(shift=sigma, its=np.zeros((L, 0), dtype=np.int64), ts=np.zeros(0), c_dot_Dz=np.zeros(0), t_elapsed=0.0)
+    return z, SOL
 
 
 @dataclass

@@ -99,3 +99,18 @@ def test_parabolic_properties_2d_L6(M):
     # to the next (E(z_{k+1}) + |u_{k+1}-u_k|^2/(2h) <= E(z_k))
     E = [float(np.dot(w, z[:, 2] / 2.0 + 0.5 * z[:, 0])) for z in sol.u[1:]]
     assert all(b <= a + 1e-6 for a, b in zip(E, E[1:]))
+
+
+@pytest.mark.parametrize("kind,L,p", [("fem1d", 3, 1.0), ("fem2d", 3, 1.0), ("fem2d", 2, 2.0)])
+def test_feasibility_phase(M, kind, L, p):
+    """SOL_feasibility (src:428-455): an infeasible start (slack too small) is repaired by the feasibility
+    phase and the main phase lands on the same z as the oracle; a feasible start keeps SOL_feasibility None."""
+    gbad = {1: lambda x: np.array([x[0], 0.2]), 2: lambda x: np.array([x[0] ** 2 + x[1] ** 2, 0.5])}
+    dim = 1 if kind == "fem1d" else 2
+    sol = getattr(M, kind + "_mpi_solve")(L=L, p=p, g=gbad[dim])
+    assert sol.SOL_feasibility is not None and sol.SOL_feasibility["shift"] > 0
+    ref = O.amgb(getattr(O, kind)(L), p=p, g=gbad[dim])
+    assert ref.SOL_feasibility is not None
+    assert abs(sol.SOL_feasibility["shift"] - ref.SOL_feasibility["shift"]) <= 1e-12 * ref.SOL_feasibility["shift"]
+    assert rel(M.mpi_to_native(sol).z, ref.z) < 1e-10
+    assert getattr(M, kind + "_mpi_solve")(L=L, p=p).SOL_feasibility is None        # src:428-430

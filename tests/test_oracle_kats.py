@@ -224,3 +224,12 @@ def test_fem3d_solve_properties():
     bnd = np.any(np.abs(np.abs(g.x) - 1.0) < 1e-14, axis=1)
     assert np.abs(z[bnd, 0] - np.sum(g.x[bnd] ** 2, axis=1)).max() < 1e-13
     assert np.all(np.diff(sol.SOL_main["c_dot_Dz"]) < 1e-9)
+
+
+def test_feasibility_phase_oracle():
+    """An infeasible start is repaired (SOL_feasibility is a record, not None: src:428-455) and the main phase
+    reaches the same z as from the default feasible start."""
+    bad = O.amgb(O.fem2d(2), p=1.5, g=lambda x: np.array([x[0] ** 2 + x[1] ** 2, 0.5]))
+    ok = O.amgb(O.fem2d(2), p=1.5)
+    assert bad.SOL_feasibility is not None and ok.SOL_feasibility is None
+    assert np.linalg.norm(bad.z - ok.z) / np.linalg.norm(ok.z) < 1e-9
