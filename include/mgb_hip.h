@@ -125,12 +125,12 @@ int mgb_amg_solve(mgb_amg a, double tol, double t0, double kappa, int maxit, int
 /* SOL_main fields (docs/src/api.md:97-101) of the last mgb_amg_solve */
 int mgb_amg_sol_info(mgb_amg a, int* nt, double* t_elapsed, double* time_factor, long long* counts4);
 int mgb_amg_sol_get(mgb_amg a, long long* its /* L x nt col-major */, double* ts, double* c_dot_Dz);
-/* live HIP-event timing of the 11 kernel classes accumulated over the last mgb_amg_solve (event pairs
+/* live HIP-event timing of the 10 kernel classes accumulated over the last mgb_amg_solve (event pairs
  * recorded on the context stream around single launches; the Cholesky classes are sampled on every 8th
  * factorisation): total ms, total algorithmic bytes, launches timed;
  * order = apply_D, barrier_f2, hessian_assemble, barrier_f1, restrict, barrier_f0,
- *         chol_panel_factor, chol_trailing_update, chol_extend_add, chol_forward, chol_backward */
-int mgb_amg_sol_kernels(mgb_amg a, double* ms11, double* bytes11, long long* launches11);
+ *         chol_front_start, chol_front_step, chol_backward_rect, chol_backward */
+int mgb_amg_sol_kernels(mgb_amg a, double* ms10, double* bytes10, long long* launches10);
 /* per-kernel device timings (HIP events on the context stream), ms and algorithmic bytes per launch:
  * order = apply_D, barrier_f2, hessian_assemble, barrier_f1, restrict, barrier_f0 */
 int mgb_amg_time_kernels(mgb_amg a, int level, int reps, double* ms6, double* bytes6);
@@ -148,6 +148,9 @@ int mgb_plan_eval_host(mgb_plan p, const double* Y /* n x nY */, double* lower_v
 /* host-only timing of the multifrontal factorisation/solve of T*vec(Y) on this level's pattern */
 int mgb_plan_chol_bench(mgb_plan p, const double* Y, int dim, int reps, double* seconds_per_factor,
                         double* seconds_per_solve, double* flops, double* front_doubles, double* residual);
+/* host-only: the nested-dissection elimination tree of this level's pattern in postorder (children first):
+ * own size, front size and parent (-1 = root) of the first min(cap, *nnodes) nodes */
+int mgb_plan_chol_tree(mgb_plan p, int dim, int cap, int* nnodes, int* ns, int* nf, int* parent);
 int mgb_chol_selftest(int nx, int ny, double* max_residual, double* flops, double* seconds);
 
 #ifdef __cplusplus

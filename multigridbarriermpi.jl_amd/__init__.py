@@ -545,8 +545,9 @@ class AMG:
         ts = np.empty(nt.value)
         cd = np.empty(nt.value)
         call("mgb_amg_sol_get", self.handle, its.ctypes.data_as(_lib.c_ll_p), dptr(ts), dptr(cd))
-        kms, kby = np.empty(11), np.empty(11)
-        kl = np.empty(11, dtype=np.int64)
+        nk = len(self.KERNEL_NAMES)
+        kms, kby = np.empty(nk), np.empty(nk)
+        kl = np.empty(nk, dtype=np.int64)
         call("mgb_amg_sol_kernels", self.handle, dptr(kms), dptr(kby), kl.ctypes.data_as(_lib.c_ll_p))
         kernels = {k: dict(ms=float(m), bytes=float(b), launches=int(c))
                    for k, m, b, c in zip(self.KERNEL_NAMES, kms, kby, kl)}
@@ -555,7 +556,7 @@ class AMG:
                     kernels=kernels)
 
     KERNEL_NAMES = ("apply_D", "barrier_f2", "hessian_assemble", "barrier_f1", "restrict", "barrier_f0",
-                    "chol_panel_factor", "chol_trailing_update", "chol_extend_add", "chol_forward", "chol_backward")
+                    "chol_front_start", "chol_front_step", "chol_backward_rect", "chol_backward")
 
     def time_kernels(self, l, reps=50):
         ms = np.empty(6)

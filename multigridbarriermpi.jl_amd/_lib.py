@@ -84,6 +84,7 @@ PROTOTYPES = {
     "mgb_plan_pattern": [H, c_i32_p, c_i32_p],
     "mgb_plan_eval_host": [H, c_dbl_p, c_dbl_p],
     "mgb_plan_chol_bench": [H, c_dbl_p, C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p],
+    "mgb_plan_chol_tree": [H, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p],
     "mgb_chol_selftest": [C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],
 }
 _SPECIAL = {"mgb_last_error": ([], C.c_char_p), "mgb_version": ([], C.c_int), "mgb_device_count": ([], C.c_int)}

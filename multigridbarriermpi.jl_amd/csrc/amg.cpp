@@ -445,8 +445,7 @@ bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st,
       hip_check(hipEventRecord(e0, ctx_.stream), "record");
     }
     KernelTimer* tm = (live_ && (st.n_factor % 8) == 1) ? &timer_ : nullptr;
-    lv.gchol.factor(ctx_.stream, lv.avals.p, tm);
-    lv.gchol.solve(ctx_.stream, lv.g.p, lv.nstep.p, tm);
+    lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g.p, lv.nstep.p, tm);
     if (live_) hip_check(hipEventRecord(e1, ctx_.stream), "record");
     launch_dot(ctx_.stream, N, lv.g.p, lv.nstep.p, partials_.p, scal_.p + 3);
     hip_check(hipMemcpyAsync(h_scal_.p + 3, scal_.p + 3, sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H inc");
@@ -748,8 +747,7 @@ bool Amg::solve_device(int l, const double* avals, const double* g, double* nste
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   lv.avals.upload(avals, lv.plan.Apat.nnz());
   lv.g_trial.upload(g, lv.plan.N);
-  lv.gchol.factor(ctx_.stream, lv.avals.p);
-  lv.gchol.solve(ctx_.stream, lv.g_trial.p, lv.nstep.p);
+  lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g_trial.p, lv.nstep.p);
   hip_check(hipMemcpyAsync(h_flag_.p, lv.gchol.fail_flag(), sizeof(int), hipMemcpyDeviceToHost, ctx_.stream), "D2H flag");
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   lv.nstep.download(nstep, lv.plan.N);

@@ -111,7 +111,7 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
 // factorisation to keep the event overhead below 1 %
 enum KernelClass {
   KC_APPLY = 0, KC_F2 = 1, KC_ASSEMBLE = 2, KC_F1 = 3, KC_RESTRICT = 4, KC_F0 = 5,
-  KC_CHOL_PANEL = 6, KC_CHOL_TRAIL = 7, KC_CHOL_EXTEND = 8, KC_CHOL_FWD = 9, KC_CHOL_BWD = 10, KC_COUNT = 11
+  KC_CHOL_START = 6, KC_CHOL_STEP = 7, KC_CHOL_BWD_RECT = 8, KC_CHOL_BWD = 9, KC_COUNT = 10
 };
 
 constexpr double kFracToBoundary = 0.1;   // == oracle FRAC_TO_BOUNDARY

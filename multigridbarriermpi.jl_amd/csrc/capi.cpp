@@ -615,13 +615,13 @@ int mgb_amg_sol_get(mgb_amg a, long long* its, double* ts, double* c_dot_Dz) {
     if (c_dot_Dz) std::copy(a->stats.c_dot_Dz.begin(), a->stats.c_dot_Dz.end(), c_dot_Dz);
   });
 }
-int mgb_amg_sol_kernels(mgb_amg a, double* ms11, double* bytes11, long long* launches11) {
+int mgb_amg_sol_kernels(mgb_amg a, double* ms10, double* bytes10, long long* launches10) {
   return guard([&] {
     need(a, "null amg");
     for (int i = 0; i < KC_COUNT; ++i) {
-      if (ms11) ms11[i] = a->stats.kern_ms[i];
-      if (bytes11) bytes11[i] = a->stats.kern_bytes[i];
-      if (launches11) launches11[i] = a->stats.kern_launches[i];
+      if (ms10) ms10[i] = a->stats.kern_ms[i];
+      if (bytes10) bytes10[i] = a->stats.kern_bytes[i];
+      if (launches10) launches10[i] = a->stats.kern_launches[i];
     }
   });
 }
@@ -721,6 +721,21 @@ int mgb_plan_chol_bench(mgb_plan p, const double* Y, int dim, int reps, double* 
     if (flops) *flops = ch.factor_flops();
     if (front_doubles) *front_doubles = (double)ch.front_doubles();
     if (residual) *residual = mx / sc;
+  });
+}
+
+int mgb_plan_chol_tree(mgb_plan p, int dim, int cap, int* nnodes, int* ns, int* nf, int* parent) {
+  return guard([&] {
+    need(p && nnodes, "chol_tree: bad arguments");
+    MfChol ch;
+    ch.analyze(p->plan.Apat, p->plan.coords.data(), dim);
+    std::vector<int> a, b, c;
+    ch.tree(a, b, c);
+    *nnodes = (int)a.size();
+    const int m = std::min<int>(cap, (int)a.size());
+    if (ns) std::copy(a.begin(), a.begin() + m, ns);
+    if (nf) std::copy(b.begin(), b.begin() + m, nf);
+    if (parent) std::copy(c.begin(), c.begin() + m, parent);
   });
 }
 

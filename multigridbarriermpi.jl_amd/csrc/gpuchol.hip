@@ -1,15 +1,20 @@
 // gfx950 kernels + host schedule of the device multifrontal Cholesky (see gpuchol.hpp).
 //
-// Roofline: the trailing update is the only compute-shaped kernel (fp64 rank-32 updates on 32x32 tiles,
-// ~1.5 GFLOP per fine-level factorisation at fem2d L=7); everything else is latency bound (a dependent
-// chain of ~150 short launches per factorisation).  Fronts (225 MB at L=7) stream through L2/Infinity
-// Cache; no MFMA (fp64 dense work is small and triangular/ragged).
+// Roofline: at the benchmark sizes this solver is bound by the LENGTH of its dependent launch chain (one
+// launch per 32 pivot columns along the tallest root-to-leaf path of the elimination tree), not by HBM or
+// the fp64 pipes: ~1.5 GFLOP and ~230 MB of fronts per fine-level factorisation at fem2d L=7, all of it
+// L2 / Infinity-Cache resident.  The design therefore minimises launches and dependent global-memory
+// round trips per launch (descriptor -> operands -> results), and spends redundant flops freely (every
+// tile re-derives its two 64x32 panel blocks instead of waiting for a separate TRSM launch).  No MFMA:
+// fp64 matrix and vector peaks are equal on MI355X and the tiles are ragged / triangular.
 #include "gpuchol.hpp"
 
 #include "amg.hpp"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <numeric>
 #include <stdexcept>
 #include <string>
 
@@ -17,18 +22,14 @@ namespace mgb {
 
 namespace {
 
-constexpr int PB = 32;     // panel width
-constexpr int TB = 256;    // threads per workgroup
+constexpr int PB = 32;       // panel width
+constexpr int LP = PB + 1;   // padded LDS row length
+constexpr int TS = 64;       // trailing-update tile
+constexpr int TB = 256;      // threads per workgroup (factorisation kernels)
+constexpr int RT = 1024;     // threads per workgroup (backward_rect)
 
 void ck(hipError_t e, const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in gpuchol ") + what + ": " + hipGetErrorString(e));
-}
-
-__global__ __launch_bounds__(TB) void scatter_kernel(int n, const int* __restrict__ src,
-                                                      const long long* __restrict__ dst,
-                                                      const double* __restrict__ vals, double* fronts) {
-  for (long long k = (long long)blockIdx.x * TB + threadIdx.x; k < n; k += (long long)gridDim.x * TB)
-    fronts[dst[k]] = vals[src[k]];
 }
 
 // broadcast lane `lane` (compile-time constant) of a double through SGPRs
@@ -38,51 +39,23 @@ __device__ inline double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// parent front += child's Schur complement.  One workgroup per (child, chunk of 8 boundary columns); the two
-// child slots of a height are separate launches, so siblings never add into the same entry concurrently.
-constexpr int EA_COLS = 8;
-__global__ __launch_bounds__(TB) void extend_add_kernel(const GNode* __restrict__ nodes, const GTile* __restrict__ list,
-                                                         const int* __restrict__ ea_all, double* fronts) {
-  const GTile job = list[blockIdx.x];
-  const GNode c = nodes[job.node];
-  const GNode p = nodes[c.parent];
-  const int nb = c.nf - c.ns;
-  const int* ea = ea_all + c.bofs;
-  const double* Fc = fronts + c.off;
-  double* Fp = fronts + p.off;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b0 = job.ti * EA_COLS, b1 = min(nb, b0 + EA_COLS);
-  for (int b = b0 + wave; b < b1; b += TB / 64) {
-    const long long pc = (long long)p.nf * ea[b];
-    const double* col = Fc + (long long)c.nf * (c.ns + b) + c.ns;
-    for (int a = b + lane; a < nb; a += 64) Fp[pc + ea[a]] += col[a];
-  }
-}
-
-// Panel p of every listed front, rows [k1 + 256*slice, ...): every workgroup re-derives the Cholesky factor
-// of the ORIGINAL 32x32 diagonal block (wave-level, rows in registers, cross-lane shuffles) and its inverse,
-// so the slices of one front run concurrently without reading anything another slice writes; slice 0 stores
-// the inverse (both orientations) to the scratch the sweeps read.  L21 = F21 * L11^{-T}.
-constexpr int SLICE = TB;
-__global__ __launch_bounds__(TB) void panel_factor_kernel(const GNode* __restrict__ nodes, const GTile* __restrict__ list,
-                                                           int p, double* fronts, double* linv, int* fail) {
-  __shared__ double Ls[PB][PB + 1];
-  __shared__ double Is[PB][PB + 1];
-  const GTile job = list[blockIdx.x];
-  const GNode nd = nodes[job.node];
-  const int nf = nd.nf, k0 = p * PB, kw = min(PB, nd.ns - k0), k1 = k0 + kw;
-  double* F = fronts + nd.off;
+// Cholesky factor L of the kw x kw lower-triangular block D (LDS, D[i*LP+j], j <= i; padded with the identity
+// up to 32x32) by wave 0, in registers: lane i owns row i, column k of L is broadcast with constant-lane
+// v_readlane (no LDS round trip).  Entries right of the diagonal of a row are don't-care (their multiplier is
+// forced to 0 once k passes the row), so the update is branch-free.  The diagonal slot keeps 1/L[k][k]
+// (L[k][k] itself is never needed again): every consumer (panel TRSM, backward sweep) is a substitution that
+// multiplies by it.  Stores the block row-major to lp[32 i + j] (zero above the diagonal).  Called by every
+// thread of the workgroup (contains a barrier); D must be visible (barrier) before the call.  Lo: 32 x LP LDS
+// scratch, distinct from D.
+__device__ void factor_diag_block(const double* D, int kw, double* Lo, double* lp, int* fail) {
   const int tid = threadIdx.x;
   if (tid < 64) {
-    // lane i (< 32) owns row i of the block (padded with the identity beyond kw).  Column k of L is
-    // broadcast with constant-lane v_readlane (no LDS round trip); entries right of the diagonal of a row
-    // are don't-care (their multiplier l is forced to 0 once k passes the row), so the update is branch-free.
     const int i = tid & 31;
-    double a[PB], rdv[PB];
+    double a[PB];
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
       double v = (i == j) ? 1.0 : 0.0;
-      if (i < kw && j < kw && j <= i) v = F[(long long)nf * (k0 + j) + k0 + i];
+      if (i < kw && j < kw && j <= i) v = D[i * LP + j];
       a[j] = v;
     }
     bool bad = false;
@@ -94,224 +67,288 @@ __global__ __launch_bounds__(TB) void panel_factor_kernel(const GNode* __restric
         akk = 1.0;
       }
       const double rd = rsqrt(akk);          // 1 / L[k][k]
-      rdv[k] = rd;
-      const double l = (i > k) ? a[k] * rd : ((i == k) ? akk * rd : 0.0);
-      a[k] = l;
+      const double l = (i > k) ? a[k] * rd : 0.0;
+      a[k] = (i == k) ? rd : l;
 #pragma unroll
       for (int j = k + 1; j < PB; ++j) a[j] = fma(-l, readlane_f64(l, j), a[j]);
     }
     if (bad && tid == 0) atomicOr(fail, 1);
     if (tid < PB) {
 #pragma unroll
-      for (int j = 0; j < PB; ++j) Ls[i][j] = (j <= i) ? a[j] : 0.0;
-      // column c = i of L^{-1} by forward substitution; L entries are LDS broadcasts of OTHER rows, so
-      // make the block visible to the wave first
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (tid < PB) {
-      const int c = i;
-      double x[PB];
-#pragma unroll
-      for (int r = 0; r < PB; ++r) {
-        double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
-#pragma unroll
-        for (int m = 0; m + 1 < r; m += 2) {
-          s0 = fma(-Ls[r][m], x[m], s0);
-          s1 = fma(-Ls[r][m + 1], x[m + 1], s1);
-        }
-        if (r & 1) s0 = fma(-Ls[r][r - 1], x[r - 1], s0);
-        x[r] = (s0 + s1) * rdv[r];
-      }
-#pragma unroll
-      for (int r = 0; r < PB; ++r) Is[r][c] = (r >= c) ? x[r] : 0.0;
+      for (int j = 0; j < PB; ++j) Lo[i * LP + j] = (j <= i) ? a[j] : 0.0;
     }
   }
   __syncthreads();
-  if (job.ti == 0) {
-    double* lp = linv + nd.loff + (long long)p * 2 * PB * PB;
-    for (int idx = tid; idx < PB * PB; idx += TB) {
-      const int i = idx % PB, j = idx / PB;
-      lp[idx] = Is[i][j];                 // Linv, column-major: lp[i + 32 j] = Linv[i][j]
-      lp[PB * PB + idx] = Is[j][i];       // its transpose, column-major
-    }
-  }
-  // rows of this slice: x = f * L11^{-T}, i.e. x_j = sum_{m<=j} f_m Linv[j][m]
-  const int i = k1 + job.ti * SLICE + tid;
-  if (i < nf) {
-    double f[PB];
-#pragma unroll
-    for (int j = 0; j < PB; ++j) f[j] = (j < kw) ? F[(long long)nf * (k0 + j) + i] : 0.0;
-#pragma unroll
-    for (int j = 0; j < PB; ++j) {
-      if (j < kw) {
-        double s = 0.0;
-#pragma unroll
-        for (int m = 0; m <= j; ++m) s += f[m] * Is[j][m];
-        F[(long long)nf * (k0 + j) + i] = s;
-      }
-    }
-  }
+  for (int idx = tid; idx < PB * PB; idx += blockDim.x) lp[idx] = Lo[(idx / PB) * LP + idx % PB];
 }
 
-// C[i,j] -= sum_q L[i,k0+q] L[j,k0+q] on one 32x32 tile of the trailing lower triangle
-__global__ __launch_bounds__(TB) void trailing_update_kernel(const GNode* __restrict__ nodes,
-                                                              const GTile* __restrict__ tiles, int p, double* fronts) {
-  __shared__ double Pi[PB][PB + 1];
-  __shared__ double Pj[PB][PB + 1];
-  const GTile t = tiles[blockIdx.x];
-  const GNode nd = nodes[t.node];
-  const int nf = nd.nf, k0 = p * PB, kw = min(PB, nd.ns - k0), k1 = k0 + kw;
+// Start of a height: workgroup = 32 columns of one front.  (1) zero the lower part of the columns and put the
+// right-hand side into the extra row nf, (2) store the assembled matrix entries, (3) add the Schur complements
+// (and reduced right-hand sides) of child slot 0, then slot 1 -- every parent entry belongs to exactly one
+// workgroup, so the order of the additions is fixed -- (4) the workgroup of columns 0..31 factors the first
+// pivot block.
+__global__ __launch_bounds__(TB) void front_start_kernel(const GNode* __restrict__ nodes, const StartJob* __restrict__ jobs,
+                                                          const int* __restrict__ ea_all, const int* __restrict__ asm_src,
+                                                          const int* __restrict__ asm_pos, const double* __restrict__ vals,
+                                                          const int* __restrict__ perm, const double* __restrict__ b,
+                                                          double* fronts, double* linv, int* fail) {
+  __shared__ double sh[2 * PB * LP];
+  const StartJob job = jobs[blockIdx.x];
+  const GNode nd = nodes[job.node];
+  const int nf = nd.nf, ld = nf + 1, ns = nd.ns;
   double* F = fronts + nd.off;
-  const int r0 = k1 + PB * t.ti, c0 = k1 + PB * t.tj;
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < PB * PB; idx += TB) {
-    const int r = idx % PB, q = idx / PB;
-    Pi[r][q] = (q < kw && r0 + r < nf) ? F[(long long)nf * (k0 + q) + r0 + r] : 0.0;
-    Pj[r][q] = (q < kw && c0 + r < nf) ? F[(long long)nf * (k0 + q) + c0 + r] : 0.0;
+  const int c0 = job.chunk * PB, c1 = min(nf, c0 + PB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = c0 + wave; c < c1; c += TB / 64) {
+    double* col = F + (long long)ld * c;
+    for (int i = c + lane; i < nf; i += 64) col[i] = 0.0;
+    if (lane == 0) col[nf] = (c < ns) ? b[perm[nd.first + c]] : 0.0;
   }
   __syncthreads();
-  const int tx = tid & 15, ty = tid >> 4;
-  double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-#pragma unroll 8
-  for (int q = 0; q < PB; ++q) {
-    const double x0 = Pi[tx][q], x1 = Pi[tx + 16][q], y0 = Pj[ty][q], y1 = Pj[ty + 16][q];
-    a00 += x0 * y0;
-    a01 += x0 * y1;
-    a10 += x1 * y0;
-    a11 += x1 * y1;
-  }
-  const int i0 = r0 + tx, i1 = r0 + tx + 16, j0 = c0 + ty, j1 = c0 + ty + 16;
-  if (i0 < nf && j0 < nf && i0 >= j0) F[(long long)nf * j0 + i0] -= a00;
-  if (i0 < nf && j1 < nf && i0 >= j1) F[(long long)nf * j1 + i0] -= a01;
-  if (i1 < nf && j0 < nf && i1 >= j0) F[(long long)nf * j0 + i1] -= a10;
-  if (i1 < nf && j1 < nf && i1 >= j1) F[(long long)nf * j1 + i1] -= a11;
-}
-
-__global__ __launch_bounds__(TB) void gather_perm_kernel(int n, const int* __restrict__ perm,
-                                                          const double* __restrict__ b, double* y) {
-  for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n; i += (long long)gridDim.x * TB) y[i] = b[perm[i]];
-}
-
-__global__ __launch_bounds__(TB) void scatter_perm_kernel(int n, const int* __restrict__ perm,
-                                                           const double* __restrict__ y, double* x) {
-  for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n; i += (long long)gridDim.x * TB) x[perm[i]] = y[i];
-}
-
-// Forward sweep L u = b of one height: front-local vector u = [own | bdry] in LDS; children's boundary
-// parts are pulled in slot order, the own part is solved panel by panel with the stored block inverses,
-// then the boundary part is updated in one pass (u_bdry -= L21 u_own).
-template <int NT>
-__global__ __launch_bounds__(NT) void forward_kernel(const GNode* __restrict__ nodes, const int* __restrict__ list,
-                                                      const int* __restrict__ ea_all, const double* __restrict__ fronts,
-                                                      const double* __restrict__ linv, double* y, double* work) {
-  extern __shared__ double u[];
-  __shared__ double tmp[PB];
-  const GNode nd = nodes[list[blockIdx.x]];
-  const int nf = nd.nf, ns = nd.ns, nb = nf - ns, tid = threadIdx.x;
-  const double* F = fronts + nd.off;
-  for (int i = tid; i < nf; i += NT) u[i] = (i < ns) ? y[nd.first + i] : 0.0;
+  for (int k = job.a0 + tid; k < job.a1; k += TB) F[asm_pos[k]] = vals[asm_src[k]];
   __syncthreads();
   for (int s = 0; s < 2; ++s) {
-    if (nd.child[s] >= 0) {
-      const GNode c = nodes[nd.child[s]];
-      const int cnb = c.nf - c.ns;
+    const int ch = nd.child[s];
+    if (ch >= 0) {
+      const GNode c = nodes[ch];
+      const int cnb = c.nf - c.ns, cld = c.nf + 1;
       const int* ea = ea_all + c.bofs;
-      const double* wc = work + c.woff + c.ns;
-      for (int i = tid; i < cnb; i += NT) u[ea[i]] += wc[i];
+      const double* Fc = fronts + c.off;
+      for (int bb = job.b0[s] + wave; bb < job.b1[s]; bb += TB / 64) {
+        double* pcol = F + (long long)ld * ea[bb];
+        const double* ccol = Fc + (long long)cld * (c.ns + bb) + c.ns;
+#pragma unroll 4
+        for (int a = bb + lane; a <= cnb; a += 64) {
+          const int pr = (a < cnb) ? ea[a] : nf;      // a == cnb: the child's reduced right-hand side
+          pcol[pr] += ccol[a];
+        }
+      }
     }
     __syncthreads();
   }
-  for (int k0 = 0; k0 < ns; k0 += PB) {
-    const int kw = min(PB, ns - k0), k1 = k0 + kw;
-    if (tid < kw) {
-      const int j = tid;
-      const double* lp = linv + nd.loff + (long long)(k0 / PB) * 2 * PB * PB;    // Linv[j][m] at lp[j + 32 m]
-      double s = 0.0;
-      for (int m = 0; m <= j; ++m) s += lp[j + PB * m] * u[k0 + m];
-      tmp[j] = s;
+  if (job.chunk == 0 && ns > 0) {
+    const int kw = min(PB, ns);
+    double* D = sh;
+    for (int idx = tid; idx < PB * PB; idx += TB) {
+      const int i = idx % PB, j = idx / PB;
+      D[i * LP + j] = (i < kw && j <= i) ? F[(long long)ld * j + i] : 0.0;
     }
     __syncthreads();
-    if (tid < kw) u[k0 + tid] = tmp[tid];
-    __syncthreads();
-    for (int i = k1 + tid; i < ns; i += NT) {
-      double d = 0.0;
-      for (int j = 0; j < kw; ++j) d += F[(long long)nf * (k0 + j) + i] * u[k0 + j];
-      u[i] -= d;
-    }
-    __syncthreads();
-  }
-  for (int i = tid; i < ns; i += NT) y[nd.first + i] = u[i];
-  double* w = work + nd.woff + ns;
-  for (int i = tid; i < nb; i += NT) {
-    const double* row = F + ns + i;
-    double d0 = 0.0, d1 = 0.0;
-    int j = 0;
-    for (; j + 1 < ns; j += 2) {
-      d0 += row[(long long)nf * j] * u[j];
-      d1 += row[(long long)nf * (j + 1)] * u[j + 1];
-    }
-    if (j < ns) d0 += row[(long long)nf * j] * u[j];
-    w[i] = u[ns + i] - (d0 + d1);
+    factor_diag_block(D, kw, sh + PB * LP, linv + nd.loff, fail);
   }
 }
 
-// Backward sweep L' x = u of one height (heights descending): ancestors' entries of x are final.
+// Panel p of every front of a height that has one.  Workgroup = 64x64 tile (ti, tj) of the trailing matrix
+// (rows / columns counted from k1 = end of the panel; rows run to nf INCLUSIVE: the right-hand-side row).
+//   L_I = A[I, panel] * L11^-T, L_J likewise   (64x32 each, re-derived per tile from the stored pivot block)
+//   C[I, J] -= L_I L_J'
+// The tj == 0 tiles store L_I into the upper triangle (L[i][k] at row k, column i).  Tile (0,0) then factors
+// the next 32x32 pivot block out of its own registers, so the next launch can start from it.
+__global__ __launch_bounds__(TB) void front_step_kernel(const StepTile* __restrict__ tiles, int p, double* fronts,
+                                                         double* linv, int* fail) {
+  __shared__ double sh[2 * TS * LP + PB * LP];
+  double* AI = sh;
+  double* AJ = sh + TS * LP;
+  double* Is = sh + 2 * TS * LP;
+  const StepTile t = tiles[blockIdx.x];
+  const int nf = t.nf, ld = nf + 1, k0 = p * PB, kw = min(PB, t.ns - k0), k1 = k0 + kw;
+  double* F = fronts + t.off;
+  const int r0 = k1 + TS * t.ti, c0 = k1 + TS * t.tj;
+  const bool diag = (t.ti == t.tj);
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  // the C micro-tile (4x4 per thread) is requested first so that its latency hides behind the panel work
+  double c[4][4];
+#pragma unroll
+  for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+    for (int aq = 0; aq < 4; ++aq) {
+      const int i = r0 + tx + 16 * aq, j = c0 + ty + 16 * bq;
+      c[aq][bq] = (i <= nf && j < nf && i >= j) ? F[(long long)ld * j + i] : 0.0;
+    }
+  const double* lp = linv + t.loff;
+  for (int idx = tid; idx < PB * PB; idx += TB) Is[(idx % PB) * LP + idx / PB] = lp[idx];   // Is[j][m] = L[m][j]
+  for (int idx = tid; idx < TS * PB; idx += TB) {
+    const int r = idx % TS, q = idx / TS;
+    AI[r * LP + q] = (q < kw && r0 + r <= nf) ? F[(long long)ld * (k0 + q) + r0 + r] : 0.0;
+    if (!diag) AJ[r * LP + q] = (q < kw && c0 + r <= nf) ? F[(long long)ld * (k0 + q) + c0 + r] : 0.0;
+  }
+  __syncthreads();
+  if (tid < 2 * TS && (tid < TS || !diag)) {
+    // thread = one row of I (wave 0) or J (wave 1), in registers: X L11' = A by right-looking substitution,
+    // column j of L11 broadcast from LDS (every lane reads the same address)
+    double* A = ((tid < TS) ? AI : AJ) + (tid & (TS - 1)) * LP;
+    double f[PB];
+#pragma unroll
+    for (int m = 0; m < PB; ++m) f[m] = A[m];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const double* lj = Is + j * LP;
+      const double fj = f[j] * lj[j];          // diagonal slot holds 1 / L[j][j]
+      f[j] = fj;
+#pragma unroll
+      for (int m = j + 1; m < PB; ++m) f[m] = fma(-fj, lj[m], f[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < PB; ++m) A[m] = f[m];
+  }
+  __syncthreads();
+  const double* LI = AI;
+  const double* LJ = diag ? AI : AJ;
+  if (t.tj == 0) {
+    for (int idx = tid; idx < TS * PB; idx += TB) {
+      const int j = idx % PB, r = idx / PB, i = r0 + r;
+      if (j < kw && i <= nf) F[(long long)ld * i + k0 + j] = LI[r * LP + j];
+    }
+  }
+  double acc[4][4];
+#pragma unroll
+  for (int aq = 0; aq < 4; ++aq)
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = 0.0;
+#pragma unroll 4
+  for (int q = 0; q < PB; ++q) {
+    double x[4], y[4];
+#pragma unroll
+    for (int aq = 0; aq < 4; ++aq) x[aq] = LI[(tx + 16 * aq) * LP + q];
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq) y[bq] = LJ[(ty + 16 * bq) * LP + q];
+#pragma unroll
+    for (int aq = 0; aq < 4; ++aq)
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = fma(x[aq], y[bq], acc[aq][bq]);
+  }
+#pragma unroll
+  for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+    for (int aq = 0; aq < 4; ++aq) {
+      const int i = r0 + tx + 16 * aq, j = c0 + ty + 16 * bq;
+      c[aq][bq] -= acc[aq][bq];
+      if (i <= nf && j < nf && i >= j) F[(long long)ld * j + i] = c[aq][bq];
+    }
+  if (t.ti == 0 && t.tj == 0 && k1 < t.ns) {
+    __syncthreads();
+    double* D = sh;
+#pragma unroll
+    for (int aq = 0; aq < 2; ++aq)
+#pragma unroll
+      for (int bq = 0; bq < 2; ++bq) D[(tx + 16 * aq) * LP + ty + 16 * bq] = c[aq][bq];
+    __syncthreads();
+    factor_diag_block(D, min(PB, t.ns - k1), sh + TS * LP, linv + t.loff + PB * PB, fail);
+  }
+}
+
+// s_j = sum_i L[ns+i][j] x_bdry[i] for the own columns j of one front: thread = (column, slice of the boundary
+// rows); L[i][j] sits at row j of column i, so the loads of a wave are unit-stride and independent.
+template <int NT>
+__device__ inline void rect_part(const double* __restrict__ F, int ld, int ns, int nb, int j0, int jw,
+                                 const double* xb, double* red, double* out /* LDS or global, indexed by j */, bool subtract) {
+  const int tid = threadIdx.x;
+  const int nsl = NT / jw, jl = tid % jw, sl = tid / jw, j = j0 + jl;
+  double s = 0.0;
+  if (sl < nsl && j < ns) {
+    const double* col = F + (long long)ld * ns + j;
+#pragma unroll 8
+    for (int i = sl; i < nb; i += nsl) s = fma(col[(long long)ld * i], xb[i], s);
+  }
+  if (nsl > 1) {
+    red[tid] = s;
+    __syncthreads();
+    if (sl == 0)
+      for (int q = 1; q < nsl; ++q) s += red[q * jw + jl];
+  }
+  if (sl == 0 && j < ns) out[j] = subtract ? out[j] - s : s;
+}
+
+__global__ __launch_bounds__(RT) void backward_rect_kernel(const GNode* __restrict__ nodes, const RectJob* __restrict__ jobs,
+                                                            const int* __restrict__ bdry_all,
+                                                            const double* __restrict__ fronts, const double* __restrict__ y,
+                                                            double* rect) {
+  extern __shared__ double sh[];      // xb[nb] | red[RT]
+  const RectJob job = jobs[blockIdx.x];
+  const GNode nd = nodes[job.node];
+  const int nf = nd.nf, ns = nd.ns, nb = nf - ns;
+  const int* bd = bdry_all + nd.bofs;
+  double* xb = sh;
+  double* red = sh + nb;
+  for (int i = threadIdx.x; i < nb; i += RT) xb[i] = y[bd[i]];
+  __syncthreads();
+  rect_part<RT>(fronts + nd.off, nf + 1, ns, nb, job.chunk * 64, 64, xb, red, rect + nd.first, false);
+}
+
+// Backward sweep L' x = u of one height (heights descending, ancestors' entries of x are final): the forward
+// result u sits in row nf of the factored front (= column nf of the mirrored L).  Right-looking over panels:
+// x_p = L_pp^-T u_p by in-wave substitution, then u_j -= sum_{i in p} L[i][j] x_i for all earlier j
+// (thread per j, unit-stride loads, no reduction unless the panel rows are split over idle threads).
 template <int NT>
 __global__ __launch_bounds__(NT) void backward_kernel(const GNode* __restrict__ nodes, const int* __restrict__ list,
-                                                       const int* __restrict__ bdry_all,
-                                                       const double* __restrict__ fronts,
-                                                       const double* __restrict__ linv, double* y) {
-  extern __shared__ double u[];      // [0,ns): rhs -> solution ; [ns,nf): x of the boundary dofs
-  __shared__ double tmp[PB];
+                                                       const int* __restrict__ bdry_all, const double* __restrict__ fronts,
+                                                       const double* __restrict__ linv, const int* __restrict__ perm,
+                                                       const double* __restrict__ rect, int use_rect, double* y, double* x) {
+  extern __shared__ double sh[];      // u[ns] | xb[nb] | red[NT]
   const GNode nd = nodes[list[blockIdx.x]];
-  const int nf = nd.nf, ns = nd.ns, nb = nf - ns, tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int nf = nd.nf, ns = nd.ns, nb = nf - ns, ld = nf + 1, tid = threadIdx.x;
   const double* F = fronts + nd.off;
-  const int* bd = bdry_all + nd.bofs;
-  for (int i = tid; i < nf; i += NT) u[i] = (i < ns) ? y[nd.first + i] : y[bd[i - ns]];
-  __syncthreads();
-  // u_own -= L21' x_bdry : column j of L21 is contiguous
-  for (int j = wave; j < ns; j += NT / 64) {
-    const double* col = F + (long long)nf * j + ns;
-    double s = 0.0;
-    for (int i = lane; i < nb; i += 64) s += col[i] * u[ns + i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if (lane == 0) u[j] -= s;
+  double* u = sh;
+  double* xb = sh + ns;
+  double* red = sh + nf;
+  for (int i = tid; i < ns; i += NT) u[i] = F[(long long)ld * nf + i] - ((use_rect && nb > 0) ? rect[nd.first + i] : 0.0);
+  if (!use_rect && nb > 0) {      // workgroup-uniform
+    const int* bd = bdry_all + nd.bofs;
+    for (int i = tid; i < nb; i += NT) xb[i] = y[bd[i]];
+    __syncthreads();
+    const int jw = min(NT, (ns + 63) & ~63);
+    for (int j0 = 0; j0 < ns; j0 += jw) {
+      rect_part<NT>(F, ld, ns, nb, j0, jw, xb, red, u, true);
+      __syncthreads();
+    }
   }
   __syncthreads();
   const int npanel = (ns + PB - 1) / PB;
   for (int pp = npanel - 1; pp >= 0; --pp) {
     const int k0 = pp * PB, kw = min(PB, ns - k0), k1 = k0 + kw;
-    // u_p -= L[k1:ns, panel]' x[k1:ns]
-    for (int c = wave; c < kw; c += NT / 64) {
-      const double* col = F + (long long)nf * (k0 + c);
-      double s = 0.0;
-      for (int i = k1 + lane; i < ns; i += 64) s += col[i] * u[i];
+    if (tid < 64) {
+      // x_p = L_pp^-T u_p by wave 0: lane c owns x_c and column c of L_pp (row m of the stored block is
+      // unit-stride over c); right-looking from the last row, x_m broadcast with constant-lane v_readlane
+      const int c = tid & 31;
+      const double* lpp = linv + nd.loff + (long long)pp * PB * PB + c;
+      double lc[PB];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-      if (lane == 0) u[k0 + c] -= s;
+      for (int m = 0; m < PB; ++m) lc[m] = lpp[PB * m];          // L[m][c] (1/L[c][c] on the diagonal, 0 above)
+      double uc = (c < kw) ? u[k0 + c] : 0.0;
+#pragma unroll
+      for (int m = PB - 1; m >= 0; --m) {
+        const double xm = readlane_f64(uc * lc[m], m);            // lane m: u_m / L[m][m]
+        uc = (c == m) ? xm : fma(-lc[m], xm, uc);                 // lanes c > m: lc[m] == 0
+      }
+      if (tid < kw) u[k0 + c] = uc;
     }
     __syncthreads();
-    if (tid < kw) {
-      const int c = tid;     // x_c = sum_{m>=c} Linv[m][c] u_m ; transpose block: lt[c + 32 m] = Linv[m][c]
-      const double* lt = linv + nd.loff + (long long)pp * 2 * PB * PB + PB * PB;
-      double s = 0.0;
-      for (int m = c; m < kw; ++m) s += lt[c + PB * m] * u[k0 + m];
-      tmp[c] = s;
+    if (k0 > 0) {
+      const int jw = min(NT, (k0 + 63) & ~63), nsl = NT / jw;
+      for (int jb = 0; jb < k0; jb += jw) {
+        const int jl = tid % jw, sl = tid / jw, j = jb + jl;
+        double s = 0.0;
+        if (sl < nsl && j < k0) {
+#pragma unroll 8
+          for (int i = k0 + sl; i < k1; i += nsl) s = fma(F[(long long)ld * i + j], u[i], s);
+        }
+        if (nsl > 1) {      // then jw >= k0: a single jb iteration
+          red[tid] = s;
+          __syncthreads();
+          if (sl == 0)
+            for (int q = 1; q < nsl; ++q) s += red[q * jw + jl];
+        }
+        if (sl == 0 && j < k0) u[j] -= s;
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    if (tid < kw) u[k0 + tid] = tmp[tid];
-    __syncthreads();
   }
-  for (int i = tid; i < ns; i += NT) y[nd.first + i] = u[i];
-}
-
-inline int blocks_for(long long n) {
-  long long b = (n + TB - 1) / TB;
-  return (int)std::max<long long>(1, std::min<long long>(b, 2048));
+  for (int i = tid; i < ns; i += NT) {
+    const double v = u[i];
+    y[nd.first + i] = v;
+    x[perm[nd.first + i]] = v;
+  }
 }
 
 }  // namespace
@@ -336,15 +373,14 @@ void GpuChol::build(const MfChol& sym) {
   flops_ = sym.flops_;
   std::vector<GNode> nodes(nnodes_);
   std::vector<int> bdry_all, ea_all, height(nnodes_, 0);
-  long long off = 0, woff = 0, loff = 0;
+  long long off = 0, loff = 0;
   max_nf_ = 0;
   for (int t = 0; t < nnodes_; ++t) {
     const auto& nd = sym.nodes_[t];
     GNode& g = nodes[t];
     g.off = off;
-    g.woff = woff;
     g.loff = loff;
-    loff += (long long)((nd.ns + PB - 1) / PB) * 2 * PB * PB;
+    loff += (long long)((nd.ns + PB - 1) / PB) * PB * PB;
     g.nf = nd.nf();
     g.ns = nd.ns;
     g.first = nd.first;
@@ -352,34 +388,56 @@ void GpuChol::build(const MfChol& sym) {
     g.bofs = (int)bdry_all.size();
     g.child[0] = nd.children.size() > 0 ? nd.children[0] : -1;
     g.child[1] = nd.children.size() > 1 ? nd.children[1] : -1;
+    g.pad = 0;
     if (nd.children.size() > 2) throw std::runtime_error("gpuchol: elimination tree is not binary");
     bdry_all.insert(bdry_all.end(), nd.bdry.begin(), nd.bdry.end());
     ea_all.insert(ea_all.end(), nd.ea.begin(), nd.ea.end());
     if (nd.parent >= 0 && nd.ea.size() != nd.bdry.size()) throw std::runtime_error("gpuchol: ea/bdry size mismatch");
+    if (nd.parent >= 0 && !std::is_sorted(nd.ea.begin(), nd.ea.end())) throw std::runtime_error("gpuchol: ea not ascending");
     if (nd.parent < 0) ea_all.resize(bdry_all.size(), 0);
-    off += (long long)g.nf * g.nf;
-    woff += g.nf;
+    if ((long long)(g.nf + 1) * (g.nf + 1) > 2000000000LL) throw std::runtime_error("gpuchol: front too large");
+    off += (long long)(g.nf + 1) * (g.nf + 1);
     max_nf_ = std::max(max_nf_, g.nf);
     for (int c : nd.children) height[t] = std::max(height[t], height[c] + 1);   // postorder: children first
   }
-  if (off != (long long)sym.fronts_.size()) throw std::runtime_error("gpuchol: front size mismatch");
   total_front_ = off;
-  total_w_ = woff;
   nheights_ = nnodes_ ? *std::max_element(height.begin(), height.end()) + 1 : 0;
-  // assembly map
-  std::vector<int> asrc;
-  std::vector<long long> adst;
-  for (int t = 0; t < nnodes_; ++t)
-    for (size_t q = 0; q < sym.a_idx_[t].size(); ++q) {
-      asrc.push_back(sym.a_idx_[t][q]);
-      adst.push_back(nodes[t].off + sym.a_pos_[t][q]);
+  // assembly map, per node sorted by destination column, positions in the (nf+1)-leading-dimension layout
+  std::vector<int> asrc, apos;
+  std::vector<std::vector<int>> acol_ofs(nnodes_);     // per node: offsets into asrc per 32-column chunk (+1)
+  for (int t = 0; t < nnodes_; ++t) {
+    const int nf = nodes[t].nf, ld = nf + 1;
+    const size_t m = sym.a_idx_[t].size();
+    std::vector<int> ord(m);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return sym.a_pos_[t][a] / nf < sym.a_pos_[t][b] / nf; });
+    const int nch = (nf + PB - 1) / PB;
+    acol_ofs[t].assign(nch + 1, 0);
+    size_t q = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+      acol_ofs[t][ch] = (int)asrc.size();
+      while (q < m && sym.a_pos_[t][ord[q]] / nf < (ch + 1) * PB) {
+        const int pos = sym.a_pos_[t][ord[q]], col = pos / nf, row = pos % nf;
+        if (row < col) throw std::runtime_error("gpuchol: assembly entry above the diagonal");
+        asrc.push_back(sym.a_idx_[t][ord[q]]);
+        apos.push_back(ld * col + row);
+        ++q;
+      }
     }
-  nasm_ = (int)asrc.size();
+    acol_ofs[t][nch] = (int)asrc.size();
+    if (q != m) throw std::runtime_error("gpuchol: assembly entry outside the front");
+  }
   // schedule
+  static const int split_nf = [] {
+    const char* e = std::getenv("MGB_BWD_SPLIT_NF");
+    return e ? std::atoi(e) : 192;
+  }();
   std::vector<int> lists;
-  std::vector<GTile> tiles;
+  std::vector<StartJob> starts;
+  std::vector<StepTile> tiles;
+  std::vector<RectJob> rects;
   plan_.assign(nheights_, HeightPlan());
-  launches_ = 3;
+  launches_ = 0;
   for (int h = 0; h < nheights_; ++h) {
     HeightPlan& hp = plan_[h];
     hp.nodes.ofs = (int)lists.size();
@@ -394,64 +452,103 @@ void GpuChol::build(const MfChol& sym) {
       }
     lists.insert(lists.end(), mine.begin(), mine.end());
     hp.nodes.cnt = (int)mine.size();
-    hp.sweep_bytes = 0;
-    for (int t : mine) hp.sweep_bytes += ((double)nodes[t].nf * nodes[t].ns - 0.5 * nodes[t].ns * nodes[t].ns) * 8 + nodes[t].nf * 24.0;
-    for (int s = 0; s < 2; ++s) {
-      hp.ea[s].ofs = (int)tiles.size();
-      hp.ea_bytes[s] = 0;
-      for (int t : mine) {
-        const int c = nodes[t].child[s];
-        if (c < 0) continue;
-        const int nb = nodes[c].nf - nodes[c].ns;
-        hp.ea_bytes[s] += 0.5 * nb * nb * 24.0;     // read child entry, read+write parent entry
-        for (int ch = 0; ch * EA_COLS < nb; ++ch) tiles.push_back({c, (short)ch, 0});
+    // front_start jobs
+    hp.start.ofs = (int)starts.size();
+    hp.start_bytes = 0;
+    for (int t : mine) {
+      const GNode& g = nodes[t];
+      const int nch = (g.nf + PB - 1) / PB;
+      hp.start_bytes += 0.5 * g.nf * g.nf * 8.0 + (double)sym.a_idx_[t].size() * 20.0;
+      for (int ch = 0; ch < nch; ++ch) {
+        StartJob j{};
+        j.node = t;
+        j.chunk = ch;
+        j.a0 = acol_ofs[t][ch];
+        j.a1 = acol_ofs[t][ch + 1];
+        for (int s = 0; s < 2; ++s) {
+          j.b0[s] = j.b1[s] = 0;
+          const int c = g.child[s];
+          if (c < 0) continue;
+          const int* ea = ea_all.data() + nodes[c].bofs;
+          const int cnb = nodes[c].nf - nodes[c].ns;
+          j.b0[s] = (int)(std::lower_bound(ea, ea + cnb, ch * PB) - ea);
+          j.b1[s] = (int)(std::lower_bound(ea, ea + cnb, (ch + 1) * PB) - ea);
+          if (ch == 0) hp.start_bytes += 0.5 * cnb * cnb * 24.0;     // read child entry, read+write parent entry
+        }
+        starts.push_back(j);
       }
-      hp.ea[s].cnt = (int)tiles.size() - hp.ea[s].ofs;
-      if (hp.ea[s].cnt) launches_++;
     }
+    hp.start.cnt = (int)starts.size() - hp.start.ofs;
+    launches_++;
+    // front_step tiles, pivot-owning (0,0) tiles first
     const int npanel = (max_ns + PB - 1) / PB;
     for (int p = 0; p < npanel; ++p) {
-      Range rn{(int)tiles.size(), 0};
-      double pbytes = 0;
-      for (int t : mine)
-        if (nodes[t].ns > p * PB) {
-          const int k1 = std::min(nodes[t].ns, (p + 1) * PB);
-          pbytes += ((double)(nodes[t].nf - p * PB) * (k1 - p * PB)) * 16.0;   // panel read + written once
-          const int nsl = std::max(1, (nodes[t].nf - k1 + SLICE - 1) / SLICE);
-          for (int sl = 0; sl < nsl; ++sl) tiles.push_back({t, (short)sl, 0});
-        }
-      rn.cnt = (int)tiles.size() - rn.ofs;
       Range rt{(int)tiles.size(), 0};
-      for (int t : mine)
-        if (nodes[t].ns > p * PB) {
-          const int k1 = std::min(nodes[t].ns, (p + 1) * PB);
-          const int T = (nodes[t].nf - k1 + PB - 1) / PB;
-          if (T > 30000) throw std::runtime_error("gpuchol: front too large for tile index");
-          for (int ti = 0; ti < T; ++ti)
-            for (int tj = 0; tj <= ti; ++tj) tiles.push_back({t, (short)ti, (short)tj});
+      double bytes = 0;
+      for (int pass = 0; pass < 2; ++pass)
+        for (int t : mine) {
+          const GNode& g = nodes[t];
+          if (g.ns <= p * PB) continue;
+          const int k1 = std::min(g.ns, (p + 1) * PB), kw = k1 - p * PB;
+          const int Tr = (g.nf + 1 - k1 + TS - 1) / TS, Tc = std::max(1, (g.nf - k1 + TS - 1) / TS);
+          if (Tr > 30000) throw std::runtime_error("gpuchol: front too large for tile index");
+          if (pass == 0) {
+            const double tr = g.nf + 1 - k1;
+            bytes += tr * kw * 16.0 + 0.5 * tr * tr * 16.0;      // panel read + mirrored write, trailing read + write
+          }
+          for (int ti = 0; ti < Tr; ++ti)
+            for (int tj = 0; tj <= std::min(ti, Tc - 1); ++tj) {
+              const bool first = (ti == 0 && tj == 0);
+              if (first != (pass == 0)) continue;
+              StepTile st{};
+              st.off = g.off;
+              st.loff = g.loff + (long long)p * PB * PB;
+              st.nf = g.nf;
+              st.ns = g.ns;
+              st.ti = (short)ti;
+              st.tj = (short)tj;
+              tiles.push_back(st);
+            }
         }
       rt.cnt = (int)tiles.size() - rt.ofs;
-      hp.panel_nodes.push_back(rn);
-      hp.panel_bytes.push_back(pbytes);
-      hp.panel_tiles.push_back(rt);
-      launches_ += 1 + (rt.cnt ? 1 : 0);
+      hp.step.push_back(rt);
+      hp.step_bytes.push_back(bytes);
+      launches_++;
     }
+    // backward
+    hp.split = hp.max_nf > split_nf;
+    hp.rect.ofs = (int)rects.size();
+    hp.rect_bytes = hp.tri_bytes = 0;
+    for (int t : mine) {
+      const GNode& g = nodes[t];
+      const double nb = g.nf - g.ns;
+      hp.rect_bytes += nb * g.ns * 8.0 + nb * 12.0;
+      hp.tri_bytes += 0.5 * g.ns * g.ns * 8.0 + g.ns * 28.0;
+      if (hp.split && nb > 0)
+        for (int ch = 0; ch * 64 < g.ns; ++ch) rects.push_back({t, ch});
+    }
+    hp.rect.cnt = (int)rects.size() - hp.rect.ofs;
+    launches_ += 1 + (hp.rect.cnt ? 1 : 0);
   }
-  if ((size_t)max_nf_ * 8 > 150 * 1024) throw std::runtime_error("gpuchol: front exceeds the LDS budget of the sweeps");
+  if ((size_t)(max_nf_ + RT + PB) * 8 > 150 * 1024) throw std::runtime_error("gpuchol: front exceeds the LDS budget of the sweeps");
   d_nodes_ = upload(nodes);
   d_perm_ = upload(sym.perm_);
   d_bdry_ = upload(bdry_all);
   d_ea_ = upload(ea_all);
   d_asm_src_ = upload(asrc);
-  d_asm_dst_ = upload(adst);
+  d_asm_pos_ = upload(apos);
   d_lists_ = upload(lists);
+  d_start_ = upload(starts);
   d_tiles_ = upload(tiles);
+  d_rectjobs_ = upload(rects);
   ck(hipMalloc((void**)&d_fronts_, std::max<long long>(total_front_, 1) * sizeof(double)), "hipMalloc fronts");
   allocs_.push_back(d_fronts_);
+  // the mirrored-L half of every front is written before it is read, but never leave it uninitialised
+  ck(hipMemset(d_fronts_, 0, std::max<long long>(total_front_, 1) * sizeof(double)), "memset fronts");
   ck(hipMalloc((void**)&d_linv_, std::max<long long>(loff, 1) * sizeof(double)), "hipMalloc linv");
   allocs_.push_back(d_linv_);
-  ck(hipMalloc((void**)&d_work_, std::max<long long>(total_w_, 1) * sizeof(double)), "hipMalloc work");
-  allocs_.push_back(d_work_);
+  ck(hipMalloc((void**)&d_rect_, std::max(n_, 1) * sizeof(double)), "hipMalloc rect");
+  allocs_.push_back(d_rect_);
   ck(hipMalloc((void**)&d_y_, std::max(n_, 1) * sizeof(double)), "hipMalloc y");
   allocs_.push_back(d_y_);
   ck(hipMalloc((void**)&d_fail_, sizeof(int)), "hipMalloc flag");
@@ -459,72 +556,50 @@ void GpuChol::build(const MfChol& sym) {
   ck(hipMemset(d_fail_, 0, sizeof(int)), "memset");
   static bool attr_done = false;
   if (!attr_done) {
-    ck(hipFuncSetAttribute((const void*)forward_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
     ck(hipFuncSetAttribute((const void*)backward_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
-    ck(hipFuncSetAttribute((const void*)forward_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
     ck(hipFuncSetAttribute((const void*)backward_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
+    ck(hipFuncSetAttribute((const void*)backward_rect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
     attr_done = true;
   }
 }
 
-void GpuChol::factor(hipStream_t st, const double* d_vals, KernelTimer* tm) {
+void GpuChol::factor_solve(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm) {
   if (n_ == 0) return;
-  ck(hipMemsetAsync(d_fronts_, 0, total_front_ * sizeof(double), st), "memset fronts");
   ck(hipMemsetAsync(d_fail_, 0, sizeof(int), st), "memset flag");
-  hipLaunchKernelGGL(scatter_kernel, dim3(blocks_for(nasm_)), dim3(TB), 0, st, nasm_, d_asm_src_, d_asm_dst_, d_vals,
-                     d_fronts_);
   for (int h = 0; h < nheights_; ++h) {
     const HeightPlan& hp = plan_[h];
-    for (int s = 0; s < 2; ++s)
-      if (hp.ea[s].cnt) {
-        if (tm) tm->begin(st, KC_CHOL_EXTEND, hp.ea_bytes[s]);
-        hipLaunchKernelGGL(extend_add_kernel, dim3(hp.ea[s].cnt), dim3(TB), 0, st, d_nodes_, d_tiles_ + hp.ea[s].ofs,
-                           d_ea_, d_fronts_);
-        if (tm) tm->end(st);
-      }
-    for (size_t p = 0; p < hp.panel_nodes.size(); ++p) {
-      if (tm) tm->begin(st, KC_CHOL_PANEL, hp.panel_bytes[p]);
-      hipLaunchKernelGGL(panel_factor_kernel, dim3(hp.panel_nodes[p].cnt), dim3(TB), 0, st, d_nodes_,
-                         d_tiles_ + hp.panel_nodes[p].ofs, (int)p, d_fronts_, d_linv_, d_fail_);
-      if (tm) tm->end(st);
-      if (hp.panel_tiles[p].cnt) {
-        if (tm) tm->begin(st, KC_CHOL_TRAIL, hp.panel_tiles[p].cnt * 32768.0);   // 2 panel tiles + C read/write
-        hipLaunchKernelGGL(trailing_update_kernel, dim3(hp.panel_tiles[p].cnt), dim3(TB), 0, st, d_nodes_,
-                           d_tiles_ + hp.panel_tiles[p].ofs, (int)p, d_fronts_);
-        if (tm) tm->end(st);
-      }
-    }
-  }
-  ck(hipGetLastError(), "factor launches");
-}
-
-void GpuChol::solve(hipStream_t st, const double* d_b, double* d_x, KernelTimer* tm) {
-  if (n_ == 0) return;
-  hipLaunchKernelGGL(gather_perm_kernel, dim3(blocks_for(n_)), dim3(TB), 0, st, n_, d_perm_, d_b, d_y_);
-  for (int h = 0; h < nheights_; ++h) {
-    const HeightPlan& hp = plan_[h];
-    if (tm) tm->begin(st, KC_CHOL_FWD, hp.sweep_bytes);
-    if (hp.max_nf > 384)
-      hipLaunchKernelGGL(forward_kernel<1024>, dim3(hp.nodes.cnt), dim3(1024), (size_t)hp.max_nf * sizeof(double), st,
-                         d_nodes_, d_lists_ + hp.nodes.ofs, d_ea_, d_fronts_, d_linv_, d_y_, d_work_);
-    else
-      hipLaunchKernelGGL(forward_kernel<256>, dim3(hp.nodes.cnt), dim3(256), (size_t)hp.max_nf * sizeof(double), st,
-                         d_nodes_, d_lists_ + hp.nodes.ofs, d_ea_, d_fronts_, d_linv_, d_y_, d_work_);
+    if (tm) tm->begin(st, KC_CHOL_START, hp.start_bytes);
+    hipLaunchKernelGGL(front_start_kernel, dim3(hp.start.cnt), dim3(TB), 0, st, d_nodes_, d_start_ + hp.start.ofs, d_ea_,
+                       d_asm_src_, d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_linv_, d_fail_);
     if (tm) tm->end(st);
+    for (size_t p = 0; p < hp.step.size(); ++p) {
+      if (tm) tm->begin(st, KC_CHOL_STEP, hp.step_bytes[p]);
+      hipLaunchKernelGGL(front_step_kernel, dim3(hp.step[p].cnt), dim3(TB), 0, st, d_tiles_ + hp.step[p].ofs, (int)p,
+                         d_fronts_, d_linv_, d_fail_);
+      if (tm) tm->end(st);
+    }
   }
   for (int h = nheights_ - 1; h >= 0; --h) {
     const HeightPlan& hp = plan_[h];
-    if (tm) tm->begin(st, KC_CHOL_BWD, hp.sweep_bytes);
+    const int use_rect = hp.rect.cnt ? 1 : 0;
+    if (use_rect) {
+      if (tm) tm->begin(st, KC_CHOL_BWD_RECT, hp.rect_bytes);
+      hipLaunchKernelGGL(backward_rect_kernel, dim3(hp.rect.cnt), dim3(RT), (size_t)(hp.max_nf + RT) * sizeof(double), st,
+                         d_nodes_, d_rectjobs_ + hp.rect.ofs, d_bdry_, d_fronts_, d_y_, d_rect_);
+      if (tm) tm->end(st);
+    }
+    if (tm) tm->begin(st, KC_CHOL_BWD, hp.tri_bytes + (use_rect ? 0.0 : hp.rect_bytes));
     if (hp.max_nf > 384)
-      hipLaunchKernelGGL(backward_kernel<1024>, dim3(hp.nodes.cnt), dim3(1024), (size_t)hp.max_nf * sizeof(double), st,
-                         d_nodes_, d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_linv_, d_y_);
+      hipLaunchKernelGGL(backward_kernel<1024>, dim3(hp.nodes.cnt), dim3(1024), (size_t)(hp.max_nf + 1024 + PB) * sizeof(double),
+                         st, d_nodes_, d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_linv_, d_perm_, d_rect_, use_rect, d_y_,
+                         d_x);
     else
-      hipLaunchKernelGGL(backward_kernel<256>, dim3(hp.nodes.cnt), dim3(256), (size_t)hp.max_nf * sizeof(double), st,
-                         d_nodes_, d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_linv_, d_y_);
+      hipLaunchKernelGGL(backward_kernel<256>, dim3(hp.nodes.cnt), dim3(256), (size_t)(hp.max_nf + 256 + PB) * sizeof(double),
+                         st, d_nodes_, d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_linv_, d_perm_, d_rect_, use_rect, d_y_,
+                         d_x);
     if (tm) tm->end(st);
   }
-  hipLaunchKernelGGL(scatter_perm_kernel, dim3(blocks_for(n_)), dim3(TB), 0, st, n_, d_perm_, d_y_, d_x);
-  ck(hipGetLastError(), "solve launches");
+  ck(hipGetLastError(), "factor_solve launches");
 }
 
 }  // namespace mgb

@@ -4,13 +4,23 @@
 // (test/test_instrumented_solve.jl:25-28,99; tools/profile_ops.jl:117-126).  The sparsity pattern of
 // R_l'HR_l is fixed per level, so the host analysis of MfChol (nested-dissection tree, front index lists,
 // assembly / extend-add maps) is done once and uploaded; each Newton step then runs, entirely on the
-// context stream with no host round trip:
-//   scatter A-values into the (zeroed) fronts  ->  for each tree height: extend-add children, then
-//   32-wide panels: [panel factor: one workgroup per front]  [trailing update: 32x32 tiles over all fronts]
-//   forward sweep by height (front-local right-hand sides, children pulled in fixed order)
-//   backward sweep by height.
-// Everything is gather/pull form: no atomics, bitwise reproducible.  The inverse of every 32x32
-// diagonal block of L is kept in a side buffer so the sweeps are mat-vecs.
+// context stream with no host round trip, ONE dependent chain of launches:
+//
+//   for each tree height (leaves first):
+//     front_start : zero + assemble the front columns, pull both children's Schur complements (fixed
+//                   order), factor the first 32x32 pivot block
+//     front_step p: (one launch per 32-wide panel) every 64x64 tile of the trailing matrix re-derives the
+//                   panel rows it needs (L = A * L11^-T), applies the rank-32 update, and the tile that
+//                   owns the next pivot block factors it, so a panel costs one launch
+//   for each height (root first): backward sweep  L' x = u
+//
+// The right-hand side rides along as an extra row of every front (Cholesky of [A b; b' *]), so the
+// forward sweep L u = b happens inside the factorisation at no extra launch.  Fronts are stored as
+// (nf+1) x (nf+1) column-major squares: the lower triangle holds the working matrix, the upper triangle
+// receives the finished rows of L (L[i][k] at row k, column i) -- which is the layout the backward sweep
+// wants (unit-stride over k) and makes the panel write race-free.  Everything is gather/pull form:
+// no atomics, bitwise reproducible.  Every 32x32 diagonal block of L is kept (row-major, reciprocal
+// diagonal) in a side buffer for the substitutions of the panel TRSM and of the backward sweep.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -23,17 +33,30 @@ namespace mgb {
 class KernelTimer;   // amg.hpp: optional HIP-event bracketing of individual launches
 
 struct GNode {
-  long long off;      // offset of the nf x nf column-major front
-  long long woff;     // offset of the nf-long front-local work vector
-  long long loff;     // offset of this node's block inverses: per panel [Linv | Linv'] (2*32*32 doubles)
+  long long off;      // offset of the (nf+1) x (nf+1) column-major front
+  long long loff;     // offset of this node's 32x32 pivot blocks of L (one per panel)
   int nf, ns, first, parent;
   int bofs;           // offset of this node's bdry / ea lists (nb entries each)
   int child[2];       // -1 if absent
+  int pad;
 };
 
-struct GTile {
-  int node;
+struct StartJob {     // one workgroup of front_start: 32 columns of one front
+  int node, chunk;
+  int a0, a1;         // range of the (column-sorted) assembly list
+  int b0[2], b1[2];   // per child slot: range of child boundary columns that land in this chunk
+};
+
+struct StepTile {     // one workgroup of front_step: a 64x64 tile of the trailing matrix of one front
+  long long off;      // front offset
+  long long loff;     // offset of THIS panel's pivot block
+  int nf, ns;
   short ti, tj;
+  int pad;
+};
+
+struct RectJob {      // one workgroup of backward_rect: 64 own columns of one front
+  int node, chunk;
 };
 
 class GpuChol {
@@ -43,48 +66,48 @@ class GpuChol {
   GpuChol& operator=(const GpuChol&) = delete;
   ~GpuChol();
   void build(const MfChol& sym);
-  // d_vals: device lower-triangle values in the pattern order given to MfChol::analyze
-  void factor(hipStream_t st, const double* d_vals, KernelTimer* timer = nullptr);
-  // d_x = A^{-1} d_b, both device vectors in the ORIGINAL ordering (may alias)
-  void solve(hipStream_t st, const double* d_b, double* d_x, KernelTimer* timer = nullptr);
-  int* fail_flag() const { return d_fail_; }   // device int: nonzero after factor() if a pivot was not positive
+  // d_x = A^{-1} d_b: d_vals = device lower-triangle values in the pattern order given to MfChol::analyze,
+  // d_b / d_x device vectors in the ORIGINAL ordering (may alias).
+  void factor_solve(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* timer = nullptr);
+  int* fail_flag() const { return d_fail_; }   // device int: nonzero after factor_solve() if a pivot was not positive
   int size() const { return n_; }
   double front_bytes() const { return (double)total_front_ * 8; }
   double factor_flops() const { return flops_; }
-  int launches_per_factor() const { return launches_; }
+  int launches_per_solve() const { return launches_; }
 
  private:
   template <class T>
   T* upload(const std::vector<T>& v);
   int n_ = 0, nnodes_ = 0, nheights_ = 0, launches_ = 0, max_nf_ = 0;
-  long long total_front_ = 0, total_w_ = 0;
-  int nasm_ = 0;
+  long long total_front_ = 0;
   double flops_ = 0;
   // device
   double* d_fronts_ = nullptr;
-  double* d_work_ = nullptr;      // front-local vectors
-  double* d_linv_ = nullptr;      // inverses of the 32x32 diagonal blocks of L
-  double* d_y_ = nullptr;         // permuted rhs / solution
+  double* d_rect_ = nullptr;      // L21' x_bdry of the split backward sweep (n entries, new ordering)
+  double* d_linv_ = nullptr;      // 32x32 diagonal (pivot) blocks of L
+  double* d_y_ = nullptr;         // solution in the new ordering
   int* d_fail_ = nullptr;
   GNode* d_nodes_ = nullptr;
   int* d_perm_ = nullptr;
   int* d_bdry_ = nullptr;
   int* d_ea_ = nullptr;
   int* d_asm_src_ = nullptr;
-  long long* d_asm_dst_ = nullptr;
-  int* d_lists_ = nullptr;        // all node lists concatenated
-  GTile* d_tiles_ = nullptr;
+  int* d_asm_pos_ = nullptr;
+  int* d_lists_ = nullptr;        // node lists per height
+  StartJob* d_start_ = nullptr;
+  StepTile* d_tiles_ = nullptr;
+  RectJob* d_rectjobs_ = nullptr;
   // host schedule
   struct Range {
     int ofs, cnt;
   };
   struct HeightPlan {
-    Range nodes;
-    Range ea[2];
-    std::vector<Range> panel_nodes, panel_tiles;
-    std::vector<double> panel_bytes;
-    double ea_bytes[2], sweep_bytes;
+    Range nodes, start, rect;
+    std::vector<Range> step;
+    std::vector<double> step_bytes;
+    double start_bytes, rect_bytes, tri_bytes;
     int max_nf;
+    bool split;      // backward: rectangular part in its own multi-workgroup launch
   };
   std::vector<HeightPlan> plan_;
   std::vector<void*> allocs_;

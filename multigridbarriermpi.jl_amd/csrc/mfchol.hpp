@@ -30,6 +30,11 @@ class MfChol {
   double factor_flops() const { return flops_; }
   int num_nodes() const { return (int)nodes_.size(); }
   int max_front() const { return max_front_; }
+  // elimination tree in postorder: per node own size, front size and parent (-1 for roots)
+  void tree(std::vector<int>& ns, std::vector<int>& nf, std::vector<int>& parent) const {
+    ns.clear(); nf.clear(); parent.clear();
+    for (const Node& nd : nodes_) { ns.push_back(nd.ns); nf.push_back(nd.nf()); parent.push_back(nd.parent); }
+  }
 
  private:
   friend class GpuChol;   // the device factorisation reuses this symbolic structure verbatim

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Dispatch timeline of ONE device factorisation + solve (GpuChol) from a rocprofv3 kernel trace.
+
+  run:      rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 tools/chol_timeline.py run 7 1.0
+  analyse:  python3 tools/chol_timeline.py report gpurun_out/tl > gpurun_out/timeline.txt
+The report lists, for the last factor+solve of the run, every dispatch (kernel, workgroups, duration, idle gap
+since the previous dispatch ended) and the per-kernel totals."""
+import csv
+import glob
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(L, p, reps=4, kind="fem2d"):
+    import numpy as np
+    import mgb_amd as M
+    geo = getattr(M, kind + "_mpi")(L)
+    A = M.AMG(geo, p=p)
+    dim = {"fem1d": 1, "fem2d": 2, "fem3d": 3}[kind]
+    x = geo.x.to_numpy()
+    A.set_c(np.vstack([M.DEFAULT_F[dim](xi) for xi in x]))
+    A.set_z(np.vstack([M.DEFAULT_G[dim](xi) for xi in x]).reshape(-1, order="F"))
+    l = A.L - 1
+    N = A.level_size(l)[0]
+    H, lower = A.f2(l, np.zeros(N), 0.1)
+    g = A.f1(l, np.zeros(N), 0.1)
+    for _ in range(reps):
+        xs = A.solve_linear(l, lower, g)
+    r = H @ xs - g
+    print("N=%d residual %.3e" % (N, np.linalg.norm(r) / np.linalg.norm(g)))
+
+
+def report(d):
+    files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    rows = []
+    for f in files:
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
+                             int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0), int(r.get("Workgroup_Size_X", 1) or 1)))
+    rows.sort()
+    # last factorisation: from the last scatter_kernel dispatch to the end
+    starts = [i for i, r in enumerate(rows) if "scatter_kernel" in r[2] and "perm" not in r[2]]
+    i0 = starts[-1]
+    seq = rows[i0:]
+    # cut after the solve's final scatter_perm
+    for j, r in enumerate(seq):
+        if "scatter_perm" in r[2]:
+            seq = seq[:j + 1]
+            break
+    short = lambda s: s.split("(")[0].replace("mgb::(anonymous namespace)::", "").replace("void ", "")
+    tot, gaps, prev = {}, 0.0, None
+    print("# idx kernel workgroups dur_us gap_us")
+    for j, (s, e, name, grid, wg) in enumerate(seq):
+        gap = 0.0 if prev is None else (s - prev) / 1e3
+        prev = e
+        gaps += max(gap, 0.0)
+        k = short(name)
+        t = tot.setdefault(k, [0, 0.0])
+        t[0] += 1
+        t[1] += (e - s) / 1e3
+        print("%4d %-28s %6d %8.2f %7.2f" % (j, k, grid // max(wg, 1), (e - s) / 1e3, gap))
+    print("# span %.1f us, kernel time %.1f us, idle gaps %.1f us over %d dispatches" %
+          ((seq[-1][1] - seq[0][0]) / 1e3, sum(v[1] for v in tot.values()), gaps, len(seq)))
+    for k, (c, t) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+        print("# %-28s %4d launches %9.1f us  avg %7.2f" % (k, c, t, t / c))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run(int(sys.argv[2]), float(sys.argv[3]), kind=sys.argv[4] if len(sys.argv) > 4 else "fem2d")
+    else:
+        report(sys.argv[2])
