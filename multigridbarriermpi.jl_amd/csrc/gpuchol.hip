@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 #include <stdexcept>
@@ -32,6 +33,12 @@ void ck(hipError_t e, const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in gpuchol ") + what + ": " + hipGetErrorString(e));
 }
 
+// optional phase stamps (100 MHz wall clock) of workgroup 0 of every factorisation launch: MGB_CHOL_PROF=1
+#define STAMP(k)                                                                   \
+  do {                                                                             \
+    if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[k] = wall_clock64();     \
+  } while (0)
+
 // broadcast lane `lane` (compile-time constant) of a double through SGPRs
 __device__ inline double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -40,93 +47,160 @@ __device__ inline double readlane_f64(double v, int lane) {
 }
 
 // Cholesky factor L of the kw x kw lower-triangular block D (LDS, D[i*LP+j], j <= i; padded with the identity
-// up to 32x32) by wave 0, in registers: lane i owns row i, column k of L is broadcast with constant-lane
-// v_readlane (no LDS round trip).  Entries right of the diagonal of a row are don't-care (their multiplier is
-// forced to 0 once k passes the row), so the update is branch-free.  The diagonal slot keeps 1/L[k][k]
-// (L[k][k] itself is never needed again): every consumer (panel TRSM, backward sweep) is a substitution that
-// multiplies by it.  Stores the block row-major to lp[32 i + j] (zero above the diagonal).  Called by every
-// thread of the workgroup (contains a barrier); D must be visible (barrier) before the call.  Lo: 32 x LP LDS
-// scratch, distinct from D.
-__device__ void factor_diag_block(const double* D, int kw, double* Lo, double* lp, int* fail) {
+// up to 32x32) by wave 0, in registers, TWO pivot columns per round.  Lane (i, h) owns the entries of row i in
+// the column pairs (4m + 2h, 4m + 2h + 1).  Per round the three pivot-block entries are broadcast with
+// constant-lane v_readlane, every lane forms 1/L[k][k], L[k+1][k], 1/L[k+1][k+1], the owning half computes its
+// two multipliers per row, and these go through a 64-entry LDS line (one write, then conflict-free broadcast
+// reads; LDS executes a wave's accesses in order, so no barrier is needed): 16 LDS round trips per block
+// instead of a v_readlane/s_nop pair per ENTRY.  Entries right of the diagonal of a row are don't-care (their
+// multipliers are forced to 0 once k passes the row), so the update is branch-free.  The diagonal slot keeps
+// 1/L[k][k] (L[k][k] itself is never needed again): every consumer (panel TRSM, backward sweep) is a
+// substitution that multiplies by it.  Stores the block row-major to lp[32 i + j] and column-major behind it
+// (zero above the diagonal).
+// Called by every thread of the workgroup (contains a barrier); D must be visible (barrier) before the call.
+// Lo: 32 x LP LDS scratch, distinct from D.
+__device__ void factor_diag_block(const double* D, int kw, double* Lo, double* lp, int* fail, long long* prof) {
   const int tid = threadIdx.x;
   if (tid < 64) {
-    const int i = tid & 31;
-    double a[PB];
+    const int i = tid & 31, h = tid >> 5;
+    double a[PB / 2];
 #pragma unroll
-    for (int j = 0; j < PB; ++j) {
+    for (int q = 0; q < PB / 2; ++q) {
+      const int j = 4 * (q >> 1) + 2 * h + (q & 1);
       double v = (i == j) ? 1.0 : 0.0;
       if (i < kw && j < kw && j <= i) v = D[i * LP + j];
-      a[j] = v;
+      a[q] = v;
     }
     bool bad = false;
+    double* col = Lo;      // the broadcast line aliases the output block, which is only written after the loop
 #pragma unroll
-    for (int k = 0; k < PB; ++k) {
-      double akk = readlane_f64(a[k], k);
+    for (int kk = 0; kk < PB / 2; ++kk) {
+      const int k = 2 * kk, hk = kk & 1, mk = kk >> 1;
+      double akk = readlane_f64(a[2 * mk], k + 32 * hk);
+      const double ak1k = readlane_f64(a[2 * mk], k + 1 + 32 * hk);
+      const double ak1k1 = readlane_f64(a[2 * mk + 1], k + 1 + 32 * hk);
       if (!(akk > 0.0) || !isfinite(akk)) {
         bad = true;
         akk = 1.0;
       }
-      const double rd = rsqrt(akk);          // 1 / L[k][k]
-      const double l = (i > k) ? a[k] * rd : 0.0;
-      a[k] = (i == k) ? rd : l;
+      const double rd0 = rsqrt(akk);              // 1 / L[k][k]
+      const double l10 = ak1k * rd0;              // L[k+1][k]
+      double d1 = fma(-l10, l10, ak1k1);
+      if (!(d1 > 0.0) || !isfinite(d1)) {
+        bad = true;
+        d1 = 1.0;
+      }
+      const double rd1 = rsqrt(d1);               // 1 / L[k+1][k+1]
+      if (h == hk) {
+        const double l0 = (i > k) ? a[2 * mk] * rd0 : 0.0;
+        const double l1 = (i > k + 1) ? fma(-l0, l10, a[2 * mk + 1]) * rd1 : 0.0;
+        col[2 * i] = l0;
+        col[2 * i + 1] = l1;
+        a[2 * mk] = (i == k) ? rd0 : l0;
+        a[2 * mk + 1] = (i == k + 1) ? rd1 : l1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const double li0 = col[2 * i], li1 = col[2 * i + 1];
+      if (hk == 0) {      // the pair (k+2, k+3) lives in the h = 1 lanes at the same register slots
+        const double m0 = (h == 1) ? li0 : 0.0, m1 = (h == 1) ? li1 : 0.0;
+        a[2 * mk] = fma(-m1, col[2 * (k + 2) + 1], fma(-m0, col[2 * (k + 2)], a[2 * mk]));
+        a[2 * mk + 1] = fma(-m1, col[2 * (k + 3) + 1], fma(-m0, col[2 * (k + 3)], a[2 * mk + 1]));
+      }
 #pragma unroll
-      for (int j = k + 1; j < PB; ++j) a[j] = fma(-l, readlane_f64(l, j), a[j]);
+      for (int m = mk + 1; m < PB / 4; ++m) {
+        const int c = 4 * m + 2 * h;
+        a[2 * m] = fma(-li1, col[2 * c + 1], fma(-li0, col[2 * c], a[2 * m]));
+        a[2 * m + 1] = fma(-li1, col[2 * c + 3], fma(-li0, col[2 * c + 2], a[2 * m + 1]));
+      }
+      __builtin_amdgcn_wave_barrier();
     }
+    STAMP(6);
     if (bad && tid == 0) atomicOr(fail, 1);
-    if (tid < PB) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int j = 0; j < PB; ++j) Lo[i * LP + j] = (j <= i) ? a[j] : 0.0;
+    for (int q = 0; q < PB / 2; ++q) {
+      const int j = 4 * (q >> 1) + 2 * h + (q & 1);
+      Lo[i * LP + j] = (j <= i) ? a[q] : 0.0;
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < PB * PB; idx += blockDim.x) lp[idx] = Lo[(idx / PB) * LP + idx % PB];
+  for (int idx = tid; idx < PB * PB; idx += blockDim.x) {
+    lp[idx] = Lo[(idx / PB) * LP + idx % PB];               // row-major: lp[32 m + c] = L[m][c]
+    lp[PB * PB + idx] = Lo[(idx % PB) * LP + idx / PB];     // column-major copy: L[m][j] at 32 j + m
+  }
 }
 
-// Start of a height: workgroup = 32 columns of one front.  (1) zero the lower part of the columns and put the
-// right-hand side into the extra row nf, (2) store the assembled matrix entries, (3) add the Schur complements
-// (and reduced right-hand sides) of child slot 0, then slot 1 -- every parent entry belongs to exactly one
-// workgroup, so the order of the additions is fixed -- (4) the workgroup of columns 0..31 factors the first
-// pivot block.
+// Start of a height: workgroup = 32 columns of one front, in gather form.  (1) every lower entry (and the
+// right-hand-side row nf) of the columns is WRITTEN as child0 + child1 contribution (or 0), found through the
+// per-child inverse index maps (parent row -> child boundary row, -1 if absent): no read-modify-write chains,
+// the loads of all 32 columns are issued (branch-free) before their stores; (2) the assembled matrix entries and the right-hand side
+// are added; (3) the workgroup of columns 0..31 factors the first pivot block.  Every parent entry belongs to
+// exactly one workgroup and the order of the additions is fixed.
 __global__ __launch_bounds__(TB) void front_start_kernel(const GNode* __restrict__ nodes, const StartJob* __restrict__ jobs,
-                                                          const int* __restrict__ ea_all, const int* __restrict__ asm_src,
+                                                          const int* __restrict__ pinv, const int* __restrict__ asm_src,
                                                           const int* __restrict__ asm_pos, const double* __restrict__ vals,
                                                           const int* __restrict__ perm, const double* __restrict__ b,
-                                                          double* fronts, double* linv, int* fail) {
+                                                          const double* __restrict__ fronts_ro, double* fronts, double* linv,
+                                                          int* fail, long long* prof) {
   __shared__ double sh[2 * PB * LP];
+  __shared__ int cb[2][PB];
+  STAMP(0);
   const StartJob job = jobs[blockIdx.x];
   const GNode nd = nodes[job.node];
   const int nf = nd.nf, ld = nf + 1, ns = nd.ns;
   double* F = fronts + nd.off;
   const int c0 = job.chunk * PB, c1 = min(nf, c0 + PB);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c = c0 + wave; c < c1; c += TB / 64) {
-    double* col = F + (long long)ld * c;
-    for (int i = c + lane; i < nf; i += 64) col[i] = 0.0;
-    if (lane == 0) col[nf] = (c < ns) ? b[perm[nd.first + c]] : 0.0;
-  }
-  __syncthreads();
-  for (int k = job.a0 + tid; k < job.a1; k += TB) F[asm_pos[k]] = vals[asm_src[k]];
-  __syncthreads();
-  for (int s = 0; s < 2; ++s) {
-    const int ch = nd.child[s];
-    if (ch >= 0) {
-      const GNode c = nodes[ch];
-      const int cnb = c.nf - c.ns, cld = c.nf + 1;
-      const int* ea = ea_all + c.bofs;
-      const double* Fc = fronts + c.off;
-      for (int bb = job.b0[s] + wave; bb < job.b1[s]; bb += TB / 64) {
-        double* pcol = F + (long long)ld * ea[bb];
-        const double* ccol = Fc + (long long)cld * (c.ns + bb) + c.ns;
-#pragma unroll 4
-        for (int a = bb + lane; a <= cnb; a += 64) {
-          const int pr = (a < cnb) ? ea[a] : nf;      // a == cnb: the child's reduced right-hand side
-          pcol[pr] += ccol[a];
-        }
-      }
+  const int tid = threadIdx.x;
+  // child blocks (read-only here, through fronts_ro): entry (boundary row a, boundary column q) of child s at
+  // fronts_ro[boff[s] + cld[s] * q + a]; an absent child gets a valid dummy offset that is never selected
+  long long boff[2] = {nd.off, nd.off};
+  int cld[2] = {0, 0};
+  bool has[2] = {false, false};
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    if (nd.child[s] >= 0) {
+      const GNode c = nodes[nd.child[s]];
+      cld[s] = c.nf + 1;
+      boff[s] = c.off + (long long)cld[s] * c.ns + c.ns;
+      has[s] = true;
     }
-    __syncthreads();
+  const int* __restrict__ inv0 = pinv + (has[0] ? nd.iofs : 0);
+  const int* __restrict__ inv1 = pinv + (has[1] ? nd.iofs + ld : 0);
+  if (tid < 2 * PB) {
+    const int s = tid / PB, c = c0 + tid % PB;
+    cb[s][tid % PB] = (has[s] && c < c1) ? (s ? inv1 : inv0)[c] : -1;
   }
+  __syncthreads();
+  STAMP(1);
+  const double* __restrict__ B0 = fronts_ro + boff[0];
+  const double* __restrict__ B1 = fronts_ro + boff[1];
+  for (int i = c0 + tid; i <= nf; i += TB) {
+    const int ra0 = has[0] ? inv0[i] : -1, ra1 = has[1] ? inv1[i] : -1;
+    const int cend = min(c1, i + 1);       // lower triangle: columns c <= i (row nf: every column)
+    double v[PB];
+    // branch-free: every load is issued (clamped to a valid address) before any is consumed
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int q0 = cb[0][q], q1 = cb[1][q];
+      const bool ok0 = (c0 + q < cend) && ra0 >= 0 && q0 >= 0, ok1 = (c0 + q < cend) && ra1 >= 0 && q1 >= 0;
+      const double x0 = B0[ok0 ? (long long)cld[0] * q0 + ra0 : 0];
+      const double x1 = B1[ok1 ? (long long)cld[1] * q1 + ra1 : 0];
+      v[q] = (ok0 ? x0 : 0.0) + (ok1 ? x1 : 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      if (c0 + q < cend) F[(long long)ld * (c0 + q) + i] = v[q];
+  }
+  __syncthreads();
+  STAMP(2);
+  for (int k = job.a0 + tid; k < job.a1; k += TB) F[asm_pos[k]] += vals[asm_src[k]];
+  for (int c = c0 + tid; c < min(c1, ns); c += TB) F[(long long)ld * c + nf] += b[perm[nd.first + c]];
   if (job.chunk == 0 && ns > 0) {
+    __syncthreads();
+    STAMP(3);
     const int kw = min(PB, ns);
     double* D = sh;
     for (int idx = tid; idx < PB * PB; idx += TB) {
@@ -134,8 +208,10 @@ __global__ __launch_bounds__(TB) void front_start_kernel(const GNode* __restrict
       D[i * LP + j] = (i < kw && j <= i) ? F[(long long)ld * j + i] : 0.0;
     }
     __syncthreads();
-    factor_diag_block(D, kw, sh + PB * LP, linv + nd.loff, fail);
+    STAMP(5);
+    factor_diag_block(D, kw, sh + PB * LP, linv + nd.loff, fail, prof);
   }
+  STAMP(7);
 }
 
 // Panel p of every front of a height that has one.  Workgroup = 64x64 tile (ti, tj) of the trailing matrix
@@ -144,12 +220,19 @@ __global__ __launch_bounds__(TB) void front_start_kernel(const GNode* __restrict
 //   C[I, J] -= L_I L_J'
 // The tj == 0 tiles store L_I into the upper triangle (L[i][k] at row k, column i).  Tile (0,0) then factors
 // the next 32x32 pivot block out of its own registers, so the next launch can start from it.
-__global__ __launch_bounds__(TB) void front_step_kernel(const StepTile* __restrict__ tiles, int p, double* fronts,
-                                                         double* linv, int* fail) {
-  __shared__ double sh[2 * TS * LP + PB * LP];
-  double* AI = sh;
-  double* AJ = sh + TS * LP;
-  double* Is = sh + 2 * TS * LP;
+__device__ inline int tile_pos(int r) { return 4 * (r & 15) + (r >> 4); }   // LDS slot of tile row r (see below)
+
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void front_step_kernel(const StepTile* __restrict__ tiles, int p, double* fronts,
+                                                         const double* __restrict__ linv_ro, double* linv, int* fail,
+                                                         long long* prof) {
+  // panel rows of the tile, transposed: AT[q * 64 + tile_pos(r)] = (row r, panel column q).  The slot
+  // permutation puts the four rows tx, tx+16, tx+32, tx+48 of a thread's micro-tile next to each other, so
+  // the rank-32 update reads them with one 32-byte LDS access while the global accesses stay coalesced.
+  __shared__ __attribute__((aligned(32))) double sh[2 * PB * TS + PB * PB];
+  double* ATI = sh;
+  double* ATJ = sh + PB * TS;
+  double* Lc = sh + 2 * PB * TS;      // column-major pivot block: Lc[32 j + m] = L[m][j]
+  STAMP(0);
   const StepTile t = tiles[blockIdx.x];
   const int nf = t.nf, ld = nf + 1, k0 = p * PB, kw = min(PB, t.ns - k0), k1 = k0 + kw;
   double* F = fronts + t.off;
@@ -157,7 +240,51 @@ __global__ __launch_bounds__(TB) void front_step_kernel(const StepTile* __restri
   const bool diag = (t.ti == t.tj);
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
-  // the C micro-tile (4x4 per thread) is requested first so that its latency hides behind the panel work
+  for (int idx = tid; idx < PB * PB; idx += TB) Lc[idx] = linv_ro[t.loff + PB * PB + idx];
+  for (int idx = tid; idx < TS * PB; idx += TB) {
+    const int r = idx % TS, q = idx / TS;
+    ATI[q * TS + tile_pos(r)] = (q < kw && r0 + r <= nf) ? F[(long long)ld * (k0 + q) + r0 + r] : 0.0;
+    if (!diag) ATJ[q * TS + tile_pos(r)] = (q < kw && c0 + r <= nf) ? F[(long long)ld * (k0 + q) + c0 + r] : 0.0;
+  }
+  __syncthreads();
+  STAMP(1);
+  if (tid < 2 * TS && (tid < TS || !diag)) {
+    // thread = one row of I (wave 0) or J (wave 1), in registers: X L11' = A by right-looking substitution;
+    // column j of L11 is contiguous in the column-major copy, read two entries per (broadcast) LDS access
+    const int r = tid & (TS - 1);
+    double* A = ((tid < TS) ? ATI : ATJ) + tile_pos(r);
+    double f[PB];
+#pragma unroll
+    for (int m = 0; m < PB; ++m) f[m] = A[m * TS];
+    // software pipeline: column j+1 of L11 is requested (all its LDS reads in flight) before column j is
+    // consumed; the empty asm keeps the compiler from sinking the reads back next to their uses
+    double lc[2][PB];
+#pragma unroll
+    for (int m = 0; m < PB; ++m) lc[0][m] = Lc[m];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      if (j + 1 < PB) {
+#pragma unroll
+        for (int m = (j + 1) & ~1; m < PB; ++m) lc[(j + 1) & 1][m] = Lc[(j + 1) * PB + m];
+      }
+      asm volatile("" ::: "memory");
+      const double fj = f[j] * lc[j & 1][j];          // diagonal slot holds 1 / L[j][j]
+      f[j] = fj;
+#pragma unroll
+      for (int m = j + 1; m < PB; ++m) f[m] = fma(-fj, lc[j & 1][m], f[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < PB; ++m) A[m * TS] = f[m];
+    if (t.tj == 0 && tid < TS && r0 + r <= nf) {         // finished rows of L go to the mirrored (upper) half
+      double* Lrow = F + (long long)ld * (r0 + r) + k0;
+#pragma unroll
+      for (int m = 0; m < PB; ++m)
+        if (m < kw) Lrow[m] = f[m];
+    }
+  }
+  __syncthreads();
+  STAMP(2);
+  // the C micro-tile (4x4 per thread) is requested here so that its latency hides behind the rank-32 update
   double c[4][4];
 #pragma unroll
   for (int bq = 0; bq < 4; ++bq)
@@ -166,53 +293,18 @@ __global__ __launch_bounds__(TB) void front_step_kernel(const StepTile* __restri
       const int i = r0 + tx + 16 * aq, j = c0 + ty + 16 * bq;
       c[aq][bq] = (i <= nf && j < nf && i >= j) ? F[(long long)ld * j + i] : 0.0;
     }
-  const double* lp = linv + t.loff;
-  for (int idx = tid; idx < PB * PB; idx += TB) Is[(idx % PB) * LP + idx / PB] = lp[idx];   // Is[j][m] = L[m][j]
-  for (int idx = tid; idx < TS * PB; idx += TB) {
-    const int r = idx % TS, q = idx / TS;
-    AI[r * LP + q] = (q < kw && r0 + r <= nf) ? F[(long long)ld * (k0 + q) + r0 + r] : 0.0;
-    if (!diag) AJ[r * LP + q] = (q < kw && c0 + r <= nf) ? F[(long long)ld * (k0 + q) + c0 + r] : 0.0;
-  }
-  __syncthreads();
-  if (tid < 2 * TS && (tid < TS || !diag)) {
-    // thread = one row of I (wave 0) or J (wave 1), in registers: X L11' = A by right-looking substitution,
-    // column j of L11 broadcast from LDS (every lane reads the same address)
-    double* A = ((tid < TS) ? AI : AJ) + (tid & (TS - 1)) * LP;
-    double f[PB];
-#pragma unroll
-    for (int m = 0; m < PB; ++m) f[m] = A[m];
-#pragma unroll
-    for (int j = 0; j < PB; ++j) {
-      const double* lj = Is + j * LP;
-      const double fj = f[j] * lj[j];          // diagonal slot holds 1 / L[j][j]
-      f[j] = fj;
-#pragma unroll
-      for (int m = j + 1; m < PB; ++m) f[m] = fma(-fj, lj[m], f[m]);
-    }
-#pragma unroll
-    for (int m = 0; m < PB; ++m) A[m] = f[m];
-  }
-  __syncthreads();
-  const double* LI = AI;
-  const double* LJ = diag ? AI : AJ;
-  if (t.tj == 0) {
-    for (int idx = tid; idx < TS * PB; idx += TB) {
-      const int j = idx % PB, r = idx / PB, i = r0 + r;
-      if (j < kw && i <= nf) F[(long long)ld * i + k0 + j] = LI[r * LP + j];
-    }
-  }
+  const double* LI = ATI + 4 * tx;
+  const double* LJ = (diag ? ATI : ATJ) + 4 * ty;
   double acc[4][4];
 #pragma unroll
   for (int aq = 0; aq < 4; ++aq)
 #pragma unroll
     for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = 0.0;
-#pragma unroll 4
+#pragma unroll 8
   for (int q = 0; q < PB; ++q) {
-    double x[4], y[4];
-#pragma unroll
-    for (int aq = 0; aq < 4; ++aq) x[aq] = LI[(tx + 16 * aq) * LP + q];
-#pragma unroll
-    for (int bq = 0; bq < 4; ++bq) y[bq] = LJ[(ty + 16 * bq) * LP + q];
+    const double4 xv = *reinterpret_cast<const double4*>(LI + q * TS);
+    const double4 yv = *reinterpret_cast<const double4*>(LJ + q * TS);
+    const double x[4] = {xv.x, xv.y, xv.z, xv.w}, y[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
     for (int aq = 0; aq < 4; ++aq)
 #pragma unroll
@@ -226,16 +318,20 @@ __global__ __launch_bounds__(TB) void front_step_kernel(const StepTile* __restri
       c[aq][bq] -= acc[aq][bq];
       if (i <= nf && j < nf && i >= j) F[(long long)ld * j + i] = c[aq][bq];
     }
+  STAMP(3);
   if (t.ti == 0 && t.tj == 0 && k1 < t.ns) {
     __syncthreads();
+    STAMP(4);
     double* D = sh;
 #pragma unroll
     for (int aq = 0; aq < 2; ++aq)
 #pragma unroll
       for (int bq = 0; bq < 2; ++bq) D[(tx + 16 * aq) * LP + ty + 16 * bq] = c[aq][bq];
     __syncthreads();
-    factor_diag_block(D, min(PB, t.ns - k1), sh + TS * LP, linv + t.loff + PB * PB, fail);
+    STAMP(5);
+    factor_diag_block(D, min(PB, t.ns - k1), sh + PB * LP, linv + t.loff + 2 * PB * PB, fail, prof);
   }
+  STAMP(7);
 }
 
 // s_j = sum_i L[ns+i][j] x_bdry[i] for the own columns j of one front: thread = (column, slice of the boundary
@@ -311,7 +407,7 @@ __global__ __launch_bounds__(NT) void backward_kernel(const GNode* __restrict__ 
       // x_p = L_pp^-T u_p by wave 0: lane c owns x_c and column c of L_pp (row m of the stored block is
       // unit-stride over c); right-looking from the last row, x_m broadcast with constant-lane v_readlane
       const int c = tid & 31;
-      const double* lpp = linv + nd.loff + (long long)pp * PB * PB + c;
+      const double* lpp = linv + nd.loff + (long long)pp * 2 * PB * PB + c;
       double lc[PB];
 #pragma unroll
       for (int m = 0; m < PB; ++m) lc[m] = lpp[PB * m];          // L[m][c] (1/L[c][c] on the diagonal, 0 above)
@@ -372,7 +468,7 @@ void GpuChol::build(const MfChol& sym) {
   nnodes_ = (int)sym.nodes_.size();
   flops_ = sym.flops_;
   std::vector<GNode> nodes(nnodes_);
-  std::vector<int> bdry_all, ea_all, height(nnodes_, 0);
+  std::vector<int> bdry_all, ea_all, pinv, height(nnodes_, 0);
   long long off = 0, loff = 0;
   max_nf_ = 0;
   for (int t = 0; t < nnodes_; ++t) {
@@ -380,7 +476,7 @@ void GpuChol::build(const MfChol& sym) {
     GNode& g = nodes[t];
     g.off = off;
     g.loff = loff;
-    loff += (long long)((nd.ns + PB - 1) / PB) * PB * PB;
+    loff += (long long)((nd.ns + PB - 1) / PB) * 2 * PB * PB;
     g.nf = nd.nf();
     g.ns = nd.ns;
     g.first = nd.first;
@@ -388,7 +484,7 @@ void GpuChol::build(const MfChol& sym) {
     g.bofs = (int)bdry_all.size();
     g.child[0] = nd.children.size() > 0 ? nd.children[0] : -1;
     g.child[1] = nd.children.size() > 1 ? nd.children[1] : -1;
-    g.pad = 0;
+    g.iofs = -1;
     if (nd.children.size() > 2) throw std::runtime_error("gpuchol: elimination tree is not binary");
     bdry_all.insert(bdry_all.end(), nd.bdry.begin(), nd.bdry.end());
     ea_all.insert(ea_all.end(), nd.ea.begin(), nd.ea.end());
@@ -401,6 +497,25 @@ void GpuChol::build(const MfChol& sym) {
     for (int c : nd.children) height[t] = std::max(height[t], height[c] + 1);   // postorder: children first
   }
   total_front_ = off;
+  // per parent and child slot: parent front row -> child boundary row (the child's right-hand-side row for nf)
+  for (int t = 0; t < nnodes_; ++t) {
+    GNode& g = nodes[t];
+    if (g.child[0] < 0 && g.child[1] < 0) continue;
+    g.iofs = (int)pinv.size();
+    pinv.resize(pinv.size() + 2 * (size_t)(g.nf + 1), -1);
+    for (int s = 0; s < 2; ++s) {
+      const int c = g.child[s];
+      if (c < 0) continue;
+      int* iv = pinv.data() + g.iofs + (size_t)s * (g.nf + 1);
+      const int cnb = nodes[c].nf - nodes[c].ns;
+      const int* ea = ea_all.data() + nodes[c].bofs;
+      for (int a = 0; a < cnb; ++a) {
+        if (ea[a] < 0 || ea[a] >= g.nf || iv[ea[a]] != -1) throw std::runtime_error("gpuchol: bad extend-add map");
+        iv[ea[a]] = a;
+      }
+      iv[g.nf] = cnb;
+    }
+  }
   nheights_ = nnodes_ ? *std::max_element(height.begin(), height.end()) + 1 : 0;
   // assembly map, per node sorted by destination column, positions in the (nf+1)-leading-dimension layout
   std::vector<int> asrc, apos;
@@ -466,14 +581,10 @@ void GpuChol::build(const MfChol& sym) {
         j.a0 = acol_ofs[t][ch];
         j.a1 = acol_ofs[t][ch + 1];
         for (int s = 0; s < 2; ++s) {
-          j.b0[s] = j.b1[s] = 0;
           const int c = g.child[s];
-          if (c < 0) continue;
-          const int* ea = ea_all.data() + nodes[c].bofs;
-          const int cnb = nodes[c].nf - nodes[c].ns;
-          j.b0[s] = (int)(std::lower_bound(ea, ea + cnb, ch * PB) - ea);
-          j.b1[s] = (int)(std::lower_bound(ea, ea + cnb, (ch + 1) * PB) - ea);
-          if (ch == 0) hp.start_bytes += 0.5 * cnb * cnb * 24.0;     // read child entry, read+write parent entry
+          if (c < 0 || ch != 0) continue;
+          const double cnb = nodes[c].nf - nodes[c].ns;
+          hp.start_bytes += 0.5 * cnb * cnb * 8.0;     // child entry read (the parent entry write is counted above)
         }
         starts.push_back(j);
       }
@@ -502,7 +613,7 @@ void GpuChol::build(const MfChol& sym) {
               if (first != (pass == 0)) continue;
               StepTile st{};
               st.off = g.off;
-              st.loff = g.loff + (long long)p * PB * PB;
+              st.loff = g.loff + (long long)p * 2 * PB * PB;
               st.nf = g.nf;
               st.ns = g.ns;
               st.ti = (short)ti;
@@ -534,7 +645,7 @@ void GpuChol::build(const MfChol& sym) {
   d_nodes_ = upload(nodes);
   d_perm_ = upload(sym.perm_);
   d_bdry_ = upload(bdry_all);
-  d_ea_ = upload(ea_all);
+  d_pinv_ = upload(pinv);
   d_asm_src_ = upload(asrc);
   d_asm_pos_ = upload(apos);
   d_lists_ = upload(lists);
@@ -554,6 +665,11 @@ void GpuChol::build(const MfChol& sym) {
   ck(hipMalloc((void**)&d_fail_, sizeof(int)), "hipMalloc flag");
   allocs_.push_back(d_fail_);
   ck(hipMemset(d_fail_, 0, sizeof(int)), "memset");
+  if (std::getenv("MGB_CHOL_PROF")) {
+    ck(hipMalloc((void**)&d_prof_, (size_t)8 * launches_ * sizeof(long long)), "hipMalloc prof");
+    allocs_.push_back(d_prof_);
+    ck(hipMemset(d_prof_, 0, (size_t)8 * launches_ * sizeof(long long)), "memset prof");
+  }
   static bool attr_done = false;
   if (!attr_done) {
     ck(hipFuncSetAttribute((const void*)backward_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
@@ -566,16 +682,18 @@ void GpuChol::build(const MfChol& sym) {
 void GpuChol::factor_solve(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm) {
   if (n_ == 0) return;
   ck(hipMemsetAsync(d_fail_, 0, sizeof(int), st), "memset flag");
+  int nprof = 0;
   for (int h = 0; h < nheights_; ++h) {
     const HeightPlan& hp = plan_[h];
     if (tm) tm->begin(st, KC_CHOL_START, hp.start_bytes);
-    hipLaunchKernelGGL(front_start_kernel, dim3(hp.start.cnt), dim3(TB), 0, st, d_nodes_, d_start_ + hp.start.ofs, d_ea_,
-                       d_asm_src_, d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_linv_, d_fail_);
+    hipLaunchKernelGGL(front_start_kernel, dim3(hp.start.cnt), dim3(TB), 0, st, d_nodes_, d_start_ + hp.start.ofs, d_pinv_,
+                       d_asm_src_, d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_fronts_, d_linv_, d_fail_,
+                       d_prof_ ? d_prof_ + 8 * (nprof++) : nullptr);
     if (tm) tm->end(st);
     for (size_t p = 0; p < hp.step.size(); ++p) {
       if (tm) tm->begin(st, KC_CHOL_STEP, hp.step_bytes[p]);
       hipLaunchKernelGGL(front_step_kernel, dim3(hp.step[p].cnt), dim3(TB), 0, st, d_tiles_ + hp.step[p].ofs, (int)p,
-                         d_fronts_, d_linv_, d_fail_);
+                         d_fronts_, d_linv_, d_linv_, d_fail_, d_prof_ ? d_prof_ + 8 * (nprof++) : nullptr);
       if (tm) tm->end(st);
     }
   }
@@ -600,6 +718,19 @@ void GpuChol::factor_solve(hipStream_t st, const double* d_vals, const double* d
     if (tm) tm->end(st);
   }
   ck(hipGetLastError(), "factor_solve launches");
+  if (d_prof_) {      // debugging aid: phase stamps of workgroup 0 of every factorisation launch, in units of 10 ns
+    ck(hipStreamSynchronize(st), "prof sync");
+    std::vector<long long> hprof((size_t)8 * nprof);
+    ck(hipMemcpy(hprof.data(), d_prof_, hprof.size() * sizeof(long long), hipMemcpyDeviceToHost), "prof D2H");
+    std::fprintf(stderr, "[mgb chol prof] launch: load trsm update store sync Dwrite factor tail (us)\n");
+    for (int q = 0; q < nprof; ++q) {
+      const long long* v = hprof.data() + 8 * q;
+      std::fprintf(stderr, "[mgb chol prof] %3d:", q);
+      for (int k = 1; k < 8; ++k) std::fprintf(stderr, " %6.2f", (v[k] && v[k - 1]) ? (v[k] - v[k - 1]) * 0.01 : 0.0);
+      std::fprintf(stderr, "\n");
+    }
+    ck(hipMemset(d_prof_, 0, hprof.size() * sizeof(long long)), "prof reset");
+  }
 }
 
 }  // namespace mgb

@@ -38,13 +38,12 @@ struct GNode {
   int nf, ns, first, parent;
   int bofs;           // offset of this node's bdry / ea lists (nb entries each)
   int child[2];       // -1 if absent
-  int pad;
+  int iofs;           // offset of the two (nf+1)-long inverse extend-add maps (-1: leaf)
 };
 
 struct StartJob {     // one workgroup of front_start: 32 columns of one front
   int node, chunk;
   int a0, a1;         // range of the (column-sorted) assembly list
-  int b0[2], b1[2];   // per child slot: range of child boundary columns that land in this chunk
 };
 
 struct StepTile {     // one workgroup of front_step: a 64x64 tile of the trailing matrix of one front
@@ -87,10 +86,11 @@ class GpuChol {
   double* d_linv_ = nullptr;      // 32x32 diagonal (pivot) blocks of L
   double* d_y_ = nullptr;         // solution in the new ordering
   int* d_fail_ = nullptr;
+  long long* d_prof_ = nullptr;   // MGB_CHOL_PROF=1: phase stamps of workgroup 0 of every factorisation launch
   GNode* d_nodes_ = nullptr;
   int* d_perm_ = nullptr;
   int* d_bdry_ = nullptr;
-  int* d_ea_ = nullptr;
+  int* d_pinv_ = nullptr;        // per parent, per child slot: parent front row -> child boundary row
   int* d_asm_src_ = nullptr;
   int* d_asm_pos_ = nullptr;
   int* d_lists_ = nullptr;        // node lists per height

@@ -42,16 +42,20 @@ def report(d):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
                              int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0), int(r.get("Workgroup_Size_X", 1) or 1)))
     rows.sort()
-    # last factorisation: from the last scatter_kernel dispatch to the end
-    starts = [i for i, r in enumerate(rows) if "scatter_kernel" in r[2] and "perm" not in r[2]]
+    names = ("front_start_kernel", "front_step_kernel", "backward_rect_kernel", "backward_kernel")
+
+    def short(s):
+        for nm in names:
+            if nm in s:
+                return nm
+        return s.split("(")[0][-28:]
+
+    # last factor+solve: from the last front_start that does not follow a front_step to the last backward_kernel
+    ks = [short(r[2]) for r in rows]
+    starts = [i for i, k in enumerate(ks) if k == "front_start_kernel" and (i == 0 or ks[i - 1] != "front_step_kernel")]
     i0 = starts[-1]
-    seq = rows[i0:]
-    # cut after the solve's final scatter_perm
-    for j, r in enumerate(seq):
-        if "scatter_perm" in r[2]:
-            seq = seq[:j + 1]
-            break
-    short = lambda s: s.split("(")[0].replace("mgb::(anonymous namespace)::", "").replace("void ", "")
+    i1 = max(i for i, k in enumerate(ks) if k == "backward_kernel")
+    seq = rows[i0:i1 + 1]
     tot, gaps, prev = {}, 0.0, None
     print("# idx kernel workgroups dur_us gap_us")
     for j, (s, e, name, grid, wg) in enumerate(seq):
