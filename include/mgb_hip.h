@@ -43,6 +43,19 @@ int mgb_device_count(void);
 int mgb_ctx_create(int device_id, mgb_ctx* out);
 int mgb_ctx_destroy(mgb_ctx ctx);
 int mgb_ctx_synchronize(mgb_ctx ctx);
+/* Row-block sharding over `world` ranks (one process + one GPU + one mgb_ctx per rank); replaces the
+ * reference's MPI.COMM_WORLD (src:125) + HPCSparseArrays row partition (src:216-221, 259-338).  Every rank
+ * uploads the WHOLE geometry; an AMG created on a sharded context keeps the element-aligned row block
+ * mgb_shard_rows() assigns to its rank (x, w, z, Dz, c, the barrier kernels and the rows of every operator),
+ * replicates the Newton unknowns and the factorisation, and calls `fn` (sum-allreduce of `count` doubles, in
+ * place at a device pointer) for the gradient, the Hessian values and the scalar reductions.  The callback is
+ * entered with the context stream idle and must return with the result visible to it (e.g. RCCL
+ * ncclAllReduce + stream sync, MPI_Allreduce on GPU-aware MPI, torch.distributed.all_reduce).  world == 1
+ * (default) never calls it. */
+typedef int (*mgb_allreduce_fn)(void* user, double* dev_ptr, long long count);
+int mgb_ctx_set_comm(mgb_ctx ctx, int rank, int world, mgb_allreduce_fn fn, void* user);
+int mgb_ctx_comm_stats(mgb_ctx ctx, long long* calls, double* bytes);
+int mgb_shard_rows(int rank, int world, int n, int block, int* r0, int* r1);
 
 /* ---- native geometry (host, setup time) ---------------------------------------------------- *
  * fem1d / fem2d are MultiGridBarrier's geometry builders, called at src:561 and src:628 before
@@ -78,6 +91,7 @@ int mgb_spmv_add(mgb_csr A, mgb_vec x, mgb_vec y0, mgb_vec y); /* y = y0 + A*x *
 int mgb_dot(mgb_vec x, mgb_vec y, double* out);               /* dot(w,y) tools/profile_scaling.jl:102 */
 int mgb_mul(mgb_vec x, mgb_vec y, mgb_vec out);               /* w .* col, test_column_extract.jl:65 */
 int mgb_axpy(mgb_vec x, double alpha, mgb_vec y, mgb_vec out); /* out = x + alpha*y */
+int mgb_vec_allreduce_sum(mgb_vec x);                         /* sum over the ranks of a sharded context (no-op for world 1); MPI.Allreduce src:125 */
 int mgb_all_isfinite(mgb_vec x, int* out);                    /* amgb_all_isfinite src:121-133 */
 
 /* ---- AMG + barrier problem ------------------------------------------------------------------ *
@@ -94,7 +108,8 @@ int mgb_amg_create_cones(mgb_ctx ctx, mgb_geo g, int S, const char* const* state
                          int ncones, const int* nq, const int* idx_q, const int* idx_s, const int* idx_s2,
                          const double* p, mgb_amg* out);
 int mgb_amg_destroy(mgb_amg a);
-int mgb_amg_dims(mgb_amg a, int* n, int* S, int* K, int* L, int* nY);
+int mgb_amg_dims(mgb_amg a, int* n, int* S, int* K, int* L, int* nY);   /* n = LOCAL rows on a sharded context */
+int mgb_amg_local_rows(mgb_amg a, int* n_global, int* row0, int* n_local);
 int mgb_amg_level_size(mgb_amg a, int level, int* N, int* nnz_lower);
 int mgb_amg_hessian_pattern(mgb_amg a, int level, int32_t* rowptr, int32_t* colidx);  /* lower triangle of R'HR */
 int mgb_amg_set_c(mgb_amg a, const double* c);     /* n x K row-major cost (f_grid) */
@@ -146,6 +161,12 @@ int mgb_plan_pattern(mgb_plan p, int32_t* rowptr, int32_t* colidx);
  * recipe (test/test_matrix_addition.jl:39-95) in the CPU test-suite; not used by the product path */
 int mgb_plan_eval_host(mgb_plan p, const double* Y /* n x nY */, double* lower_vals);
 /* host-only timing of the multifrontal factorisation/solve of T*vec(Y) on this level's pattern */
+/* host-only: the shard of a level plan that rank `rank` of `world` keeps (rows of B / R, columns of BT / T; the
+ * pattern stays global), and host products with its B / BT -- the CPU test-suite checks with them that the
+ * shards' contributions sum to the unsharded result */
+int mgb_plan_shard(mgb_plan p, int S, int K, int rank, int world, int block, mgb_plan* out, int* r0, int* r1);
+int mgb_plan_apply_B_host(mgb_plan p, const double* s /* N */, double* Bs /* n_local K */);
+int mgb_plan_apply_BT_host(mgb_plan p, const double* v /* n_local K */, double* g /* N */);
 int mgb_plan_chol_bench(mgb_plan p, const double* Y, int dim, int reps, double* seconds_per_factor,
                         double* seconds_per_solve, double* flops, double* front_doubles, double* residual);
 /* host-only: the nested-dissection elimination tree of this level's pattern in postorder (children first):

@@ -58,12 +58,65 @@ class HPCBackend:
     def synchronize(self):
         call("mgb_ctx_synchronize", self.handle)
 
+    rank, world = 0, 1
+
+    def set_comm(self, rank: int, world: int, allreduce):
+        """Row-block sharding over `world` ranks (one process + GPU per rank), the
+        counterpart of the reference's MPI.COMM_WORLD (src:125).  `allreduce(ptr, count)` must sum-allreduce
+        `count` fp64 values in place at the DEVICE pointer `ptr` over all ranks and return only when the
+        result is visible to other streams; see `torch_allreduce`.  AMGs created afterwards on this backend
+        keep only their rank's rows."""
+
+        def thunk(_user, ptr, count):
+            try:
+                allreduce(int(ptr), int(count))
+                return 0
+            except Exception as exc:       # never let an exception cross the C boundary
+                import sys
+                print("mgb allreduce callback failed: %r" % (exc,), file=sys.stderr)
+                return 1
+
+        self._allreduce_cb = _lib.ALLREDUCE_FN(thunk)     # keep the trampoline alive
+        call("mgb_ctx_set_comm", self.handle, int(rank), int(world), self._allreduce_cb, None)
+        self.rank, self.world = int(rank), int(world)
+
+    def comm_stats(self):
+        n, b = C.c_longlong(), C.c_double()
+        call("mgb_ctx_comm_stats", self.handle, C.byref(n), C.byref(b))
+        return dict(calls=n.value, bytes=b.value)
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):
                 _lib.load().mgb_ctx_destroy(self.handle)
         except Exception:
             pass
+
+
+def torch_allreduce(dist, device: int, group=None):
+    """allreduce callback for HPCBackend.set_comm on top of torch.distributed (plumbing only): backend "nccl"
+    (= RCCL over xGMI) reduces in place on the device buffer; any other backend (gloo) stages through the
+    host, which is what the single-GPU / CPU rehearsals of the sharded path use."""
+    import torch
+
+    class _Raw:
+        def __init__(self, ptr, count):
+            self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False),
+                                             "version": 2, "strides": None}
+
+    on_device = dist.get_backend(group) == "nccl"
+
+    def allreduce(ptr, count):
+        t = torch.as_tensor(_Raw(ptr, count), device=torch.device("cuda", device))
+        if on_device:
+            dist.all_reduce(t, group=group)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, group=group)
+            t.copy_(h)
+        torch.cuda.synchronize(device)
+
+    return allreduce
 
 
 _BACKENDS: Dict[int, HPCBackend] = {}
@@ -454,7 +507,12 @@ class AMG:
         self.handle = h
         n, S, K_, L, nY = (C.c_int() for _ in range(5))
         call("mgb_amg_dims", h, C.byref(n), C.byref(S), C.byref(K_), C.byref(L), C.byref(nY))
-        self.n, self.S, self.K, self.L, self.nY = n.value, S.value, K_.value, L.value, nY.value
+        self.S, self.K, self.L, self.nY = S.value, K_.value, L.value, nY.value
+        ng, r0, nl = C.c_int(), C.c_int(), C.c_int()
+        call("mgb_amg_local_rows", h, C.byref(ng), C.byref(r0), C.byref(nl))
+        # n = global rows (what set_c / set_z / get_z exchange on every rank); a sharded AMG (backend.set_comm)
+        # evaluates apply_D on its own rows [row0, row0 + n_local) only
+        self.n, self.row0, self.n_local = ng.value, r0.value, nl.value
 
     def level_size(self, l):
         N, nz = C.c_int(), C.c_int()
@@ -485,9 +543,21 @@ class AMG:
 
     def apply_D(self, l, s):
         s = f64(s)
-        out = np.empty((self.n, self.K))
+        out = np.empty((self.n_local, self.K))
         call("mgb_amg_apply_D", self.handle, l, dptr(s), dptr(out))
         return out
+
+    def apply_D_global(self, l, s):
+        """apply_D on all n rows on every rank (a sharded AMG gathers the row blocks by summation)."""
+        loc = self.apply_D(l, s)
+        backend = self.geometry.x.backend
+        if backend.world == 1:
+            return loc
+        full = np.zeros((self.n, self.K))
+        full[self.row0:self.row0 + self.n_local] = loc
+        v = HPCVector(full.reshape(-1), backend)
+        call("mgb_vec_allreduce_sum", v.handle)
+        return v.to_numpy().reshape(self.n, self.K)
 
     def f0(self, l, s, t, parts=False):
         s = f64(s)
@@ -615,7 +685,7 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
         names = [sv[0] for sv in M.state_variables]
         if op != "id" or dict(M.state_variables)[var] != "full":
             raise NotImplementedError("amgb: feasibility phase needs the cone's slack to be `id` of a :full variable")
-        Dz = M.apply_D(M.L - 1, np.zeros(Nf))
+        Dz = M.apply_D_global(M.L - 1, np.zeros(Nf))
         q2 = np.sum(Dz[:, idx[:-1]] ** 2, axis=1)
         sigma = 1.0 + float(np.max(q2 ** (p / 2.0) - Dz[:, idx[-1]]))
         z0[:, names.index(var)] += sigma

@@ -15,6 +15,8 @@ c_dbl_p = C.POINTER(C.c_double)
 c_ll_p = C.POINTER(C.c_longlong)
 c_str_arr = C.POINTER(C.c_char_p)
 H = C.c_void_p
+# mgb_allreduce_fn: int (*)(void* user, double* dev_ptr, long long count); the pointer is passed as an integer
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong)
 
 
 class MGBError(RuntimeError):
@@ -28,6 +30,9 @@ PROTOTYPES = {
     "mgb_ctx_create": [C.c_int, C.POINTER(H)],
     "mgb_ctx_destroy": [H],
     "mgb_ctx_synchronize": [H],
+    "mgb_ctx_set_comm": [H, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p],
+    "mgb_ctx_comm_stats": [H, c_ll_p, c_dbl_p],
+    "mgb_shard_rows": [C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p],
     "mgb_fem1d_native": [C.c_int, C.POINTER(H)],
     "mgb_fem2d_native": [C.c_int, c_dbl_p, C.c_int, C.POINTER(H)],
     "mgb_fem3d_native": [C.c_int, C.c_int, C.POINTER(H)],
@@ -51,6 +56,7 @@ PROTOTYPES = {
     "mgb_dot": [H, H, c_dbl_p],
     "mgb_mul": [H, H, H],
     "mgb_axpy": [H, C.c_double, H, H],
+    "mgb_vec_allreduce_sum": [H],
     "mgb_all_isfinite": [H, c_int_p],
     "mgb_amg_create": [H, H, C.c_int, c_str_arr, C.c_int, c_str_arr, C.c_int, c_int_p, C.c_int, C.c_double,
                        C.POINTER(H)],
@@ -58,6 +64,7 @@ PROTOTYPES = {
                              c_dbl_p, C.POINTER(H)],
     "mgb_amg_destroy": [H],
     "mgb_amg_dims": [H, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p],
+    "mgb_amg_local_rows": [H, c_int_p, c_int_p, c_int_p],
     "mgb_amg_level_size": [H, C.c_int, c_int_p, c_int_p],
     "mgb_amg_hessian_pattern": [H, C.c_int, c_i32_p, c_i32_p],
     "mgb_amg_set_c": [H, c_dbl_p],
@@ -83,6 +90,9 @@ PROTOTYPES = {
     "mgb_plan_sizes": [H, c_int_p, c_int_p, c_int_p, c_int_p],
     "mgb_plan_pattern": [H, c_i32_p, c_i32_p],
     "mgb_plan_eval_host": [H, c_dbl_p, c_dbl_p],
+    "mgb_plan_shard": [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), c_int_p, c_int_p],
+    "mgb_plan_apply_B_host": [H, c_dbl_p, c_dbl_p],
+    "mgb_plan_apply_BT_host": [H, c_dbl_p, c_dbl_p],
     "mgb_plan_chol_bench": [H, c_dbl_p, C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p],
     "mgb_plan_chol_tree": [H, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p],
     "mgb_chol_selftest": [C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],

@@ -27,6 +27,55 @@ Ctx::~Ctx() {
   if (stream) (void)hipStreamDestroy(stream);
 }
 
+void Ctx::allreduce_sum(double* dev_ptr, long long count) {
+  if (world <= 1 || count <= 0) return;
+  if (!allreduce) throw std::runtime_error("mgb: sharded context without an allreduce callback");
+  hip_check(hipStreamSynchronize(stream), "sync before allreduce");
+  const int rc = allreduce(allreduce_user, dev_ptr, count);
+  if (rc != 0) throw std::runtime_error("mgb: allreduce callback failed with code " + std::to_string(rc));
+  n_allreduce++;
+  allreduce_bytes += 8.0 * count;
+}
+
+// ------------------------------------------------------------------ row-block sharding
+
+void shard_rows(int rank, int world, int n, int block, int* r0, int* r1) {
+  if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("shard: bad rank / world");
+  if (block < 1 || n % block) throw std::runtime_error("shard: rows are not a multiple of the element block");
+  const long long nel = n / block;
+  if (nel < world) throw std::runtime_error("shard: fewer elements than ranks");
+  *r0 = (int)(nel * rank / world) * block;
+  *r1 = (int)(nel * (rank + 1) / world) * block;
+}
+
+Csr shard_dstack(const Csr& Dstack, int n, int S, int K, int r0, int r1) {
+  const int nl = r1 - r0;
+  std::vector<int> map((size_t)n * S, -1);      // z index sv*n + node -> sv*nl + (node - r0)
+  for (int sv = 0; sv < S; ++sv)
+    for (int q = r0; q < r1; ++q) map[(size_t)sv * n + q] = sv * nl + (q - r0);
+  // strict: apply_D must not need a halo (the operators are element-local)
+  return col_remap(row_block(Dstack, r0 * K, r1 * K), map, nl * S, true);
+}
+
+LevelPlan shard_level_plan(const LevelPlan& full, int n, int S, int K, int nY, int r0, int r1) {
+  const int nl = r1 - r0;
+  LevelPlan pl;
+  pl.N = full.N;
+  pl.Apat = full.Apat;
+  pl.coords = full.coords;
+  pl.B = row_block(full.B, r0 * K, r1 * K);
+  pl.BT = transpose(pl.B);
+  std::vector<int> pick;
+  for (int sv = 0; sv < S; ++sv)
+    for (int q = r0; q < r1; ++q) pick.push_back(sv * n + q);
+  pl.R = row_select(full.R, pick);
+  std::vector<int> map((size_t)n * nY, -1);     // Y index q*nY + slot -> (q - r0)*nY + slot
+  for (int q = r0; q < r1; ++q)
+    for (int y = 0; y < nY; ++y) map[(size_t)q * nY + y] = (q - r0) * nY + y;
+  pl.T = col_remap(full.T, map, nl * nY, false);
+  return pl;
+}
+
 static int pick_group(const Csr& A) {
   if (A.rows == 0) return 1;
   double avg = (double)A.nnz() / A.rows;
@@ -248,10 +297,18 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
       if (S.col(a) < 0 || S.col(a) >= P.K) throw std::runtime_error("amg: barrier index out of range");
   }
   if ((int)g.w.size() != n_ || (int)g.x.size() != n_ * g.dim) throw std::runtime_error("amg: geometry x/w size mismatch");
+  ng_ = g.n;
   Csr Dstack = build_dstack(g, spec);
-  Dstack_.upload(Dstack);
-  w_.upload(g.w.data(), n_);
-  w_min_ = *std::min_element(g.w.begin(), g.w.end());
+  w_min_ = *std::min_element(g.w.begin(), g.w.end());      // global: every rank holds the whole geometry
+  if (ctx_.world > 1) {
+    int r1 = 0;
+    shard_rows(ctx_.rank, ctx_.world, ng_, g.block, &r0_, &r1);
+    n_ = r1 - r0_;
+    Dstack_.upload(shard_dstack(Dstack, ng_, S_, P.K, r0_, r1));
+  } else {
+    Dstack_.upload(Dstack);
+  }
+  w_.upload(g.w.data() + r0_, n_);
   const int K = P.K, nY = P.nY();
   c_.alloc((size_t)n_ * K);
   z_.alloc((size_t)n_ * S_);
@@ -292,6 +349,7 @@ Amg::Level& Amg::level(int l) {
   if (lv.built) return lv;
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
   lv.plan = build_level_plan(geo_, spec_, dstack_host_, l, P_);
+  if (ctx_.world > 1) lv.plan = shard_level_plan(lv.plan, ng_, S_, P_.K, P_.nY(), r0_, r0_ + n_);
   lv.R.upload(lv.plan.R);
   lv.B.upload(lv.plan.B);
   lv.BT.upload(lv.plan.BT);
@@ -316,16 +374,32 @@ Amg::Level& Amg::level(int l) {
 
 const LevelPlan& Amg::plan(int l) { return level(l).plan; }
 
-void Amg::set_c(const double* c_host) { c_.upload(c_host, (size_t)n_ * P_.K); }
+// c, z arrive / leave in the GLOBAL layout on every rank; a sharded Amg keeps its own rows
+void Amg::set_c(const double* c_host) { c_.upload(c_host + (size_t)r0_ * P_.K, (size_t)n_ * P_.K); }
 
 void Amg::set_z(const double* z_host) {
-  z_.upload(z_host, (size_t)n_ * S_);
+  for (int sv = 0; sv < S_; ++sv)
+    hip_check(hipMemcpy(z_.p + (size_t)sv * n_, z_host + (size_t)sv * ng_ + r0_, (size_t)n_ * sizeof(double),
+                        hipMemcpyHostToDevice), "H2D z");
   refresh_dz0();
 }
 
 void Amg::get_z(double* z_host) {
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
-  z_.download(z_host, (size_t)n_ * S_);
+  if (ctx_.world <= 1) {
+    z_.download(z_host, (size_t)n_ * S_);
+    return;
+  }
+  // gather by summation: every rank contributes its rows to a zeroed global vector
+  DevBuf<double> zg;
+  zg.alloc((size_t)ng_ * S_);
+  hip_check(hipMemsetAsync(zg.p, 0, zg.n * sizeof(double), ctx_.stream), "memset zg");
+  for (int sv = 0; sv < S_; ++sv)
+    hip_check(hipMemcpyAsync(zg.p + (size_t)sv * ng_ + r0_, z_.p + (size_t)sv * n_, (size_t)n_ * sizeof(double),
+                             hipMemcpyDeviceToDevice, ctx_.stream), "D2D z");
+  ctx_.allreduce_sum(zg.p, (long long)zg.n);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync");
+  zg.download(z_host, zg.n);
 }
 
 static double csr_bytes(const DevCsr& A, bool y0) {
@@ -395,6 +469,7 @@ double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts, cons
   // phi_ref == nullptr: start of a Newton solve (records phi of the iterate); otherwise a line-search trial
   launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, phi_ref, kFracToBoundary, phi_out, partials_.p, scal_.p);
   timer_.end(ctx_.stream);
+  ctx_.allreduce_sum(scal_.p, 2);      // sharded: +inf (a row left the cone on some rank) survives the sum
   hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
   sync_collect("sync f0");
   if (parts) {
@@ -413,6 +488,7 @@ double Amg::dev_f1(Level& lv, const double* s_dev, double t, bool reuse_dz, doub
   timer_.begin(ctx_.stream, KC_RESTRICT, csr_bytes(lv.BT.view, false));
   launch_spmv(ctx_.stream, lv.BT.view, v_.p, nullptr, g_out);
   timer_.end(ctx_.stream);
+  ctx_.allreduce_sum(g_out, lv.plan.N);      // sharded: interface dofs are summed across the row blocks
   launch_dot(ctx_.stream, lv.plan.N, g_out, g_out, partials_.p, scal_.p + 2);
   hip_check(hipMemcpyAsync(h_scal_.p + 2, scal_.p + 2, sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H gg");
   if (host_solve_)
@@ -434,6 +510,7 @@ bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st,
   timer_.begin(ctx_.stream, KC_ASSEMBLE, csr_bytes(lv.T.view, false));
   launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
   timer_.end(ctx_.stream);
+  ctx_.allreduce_sum(lv.avals.p, nnzA);      // sharded: every rank then factors the same replicated matrix
   st.n_f2++;
   st.n_factor++;
   if (!host_solve_) {
@@ -624,6 +701,7 @@ bool Amg::amgb_step(double t, double lam_tol, int max_newton, std::vector<long l
 
 double Amg::c_dot_dz() {
   launch_barrier_f0(ctx_.stream, n_, P_, Dz0_.p, w_.p, c_.p, nullptr, 0.0, nullptr, partials_.p, scal_.p);
+  ctx_.allreduce_sum(scal_.p, 2);
   hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   return h_scal_.p[1];
@@ -730,6 +808,7 @@ void Amg::f2(int l, const double* s_host, double t, double* avals_host) {
   dev_apply(lv, lv.s_trial.p);
   launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p);
   launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
+  ctx_.allreduce_sum(lv.avals.p, lv.plan.Apat.nnz());
   hip_check(hipStreamSynchronize(ctx_.stream), "sync f2");
   lv.avals.download(avals_host, lv.plan.Apat.nnz());
 }

@@ -27,11 +27,23 @@ namespace mgb {
 
 void hip_check(hipError_t e, const char* what);
 
+// sum-allreduce of `count` doubles at the device pointer, in place, over the ranks of a row-block sharded
+// job.  Called with the context stream idle; must return with the result visible to that stream.
+typedef int (*AllreduceFn)(void* user, double* dev_ptr, long long count);
+
 struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // row-block sharding: replaces the reference's MPI.COMM_WORLD (src:125) + HPCSparseArrays
+  // row partition.  world == 1: single GPU, no collective is ever called.
+  int rank = 0, world = 1;
+  AllreduceFn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+  long long n_allreduce = 0;
+  double allreduce_bytes = 0;
   explicit Ctx(int dev);
   ~Ctx();
+  void allreduce_sum(double* dev_ptr, long long count);
 };
 
 template <class T>
@@ -103,6 +115,12 @@ struct LevelPlan {
   std::vector<double> coords;  // N x dim
 };
 
+// Row-block shard [r0, r1) of the node rows (element aligned): local rows of B / R, matching columns of BT / T;
+// N, Apat and coords stay global (the Newton unknowns and the factorisation are replicated on every rank).
+void shard_rows(int rank, int world, int n, int block, int* r0, int* r1);
+LevelPlan shard_level_plan(const LevelPlan& full, int n, int S, int K, int nY, int r0, int r1);
+Csr shard_dstack(const Csr& Dstack, int n, int S, int K, int r0, int r1);
+
 Csr build_dstack(const GeometryHost& g, const AmgSpec& spec);
 LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr& Dstack, int level,
                            const BarrierParams& P);
@@ -165,7 +183,9 @@ class KernelTimer {
 class Amg {
  public:
   Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierParams& P);
-  int n() const { return n_; }
+  int n() const { return n_; }                 // local rows (= global rows when not sharded)
+  int n_global() const { return ng_; }
+  int row0() const { return r0_; }
   int S() const { return S_; }
   int K() const { return P_.K; }
   int L() const { return (int)levels_.size(); }
@@ -228,6 +248,7 @@ class Amg {
 
   Ctx& ctx_;
   int n_ = 0, S_ = 0;
+  int ng_ = 0, r0_ = 0;           // global rows, first local row
   BarrierParams P_;
   AmgSpec spec_;
   GeometryHost geo_;              // kept for lazy level construction

@@ -204,6 +204,29 @@ int mgb_ctx_synchronize(mgb_ctx ctx) {
   });
 }
 
+int mgb_ctx_set_comm(mgb_ctx ctx, int rank, int world, mgb_allreduce_fn fn, void* user) {
+  return guard([&] {
+    need(ctx && world >= 1 && rank >= 0 && rank < world && (world == 1 || fn), "ctx_set_comm: bad arguments");
+    ctx->ctx.rank = rank;
+    ctx->ctx.world = world;
+    ctx->ctx.allreduce = fn;
+    ctx->ctx.allreduce_user = user;
+  });
+}
+int mgb_ctx_comm_stats(mgb_ctx ctx, long long* calls, double* bytes) {
+  return guard([&] {
+    need(ctx, "null ctx");
+    if (calls) *calls = ctx->ctx.n_allreduce;
+    if (bytes) *bytes = ctx->ctx.allreduce_bytes;
+  });
+}
+int mgb_shard_rows(int rank, int world, int n, int block, int* r0, int* r1) {
+  return guard([&] {
+    need(r0 && r1, "shard_rows: null output");
+    shard_rows(rank, world, n, block, r0, r1);
+  });
+}
+
 int mgb_fem1d_native(int L, mgb_geo* out) {
   return guard([&] {
     need(out, "null out");
@@ -424,6 +447,12 @@ int mgb_axpy(mgb_vec x, double alpha, mgb_vec y, mgb_vec out) {
     launch_waxpby(x->ctx->ctx.stream, x->n, x->buf.p, alpha, y->buf.p, out->buf.p);
   });
 }
+int mgb_vec_allreduce_sum(mgb_vec x) {
+  return guard([&] {
+    need(x, "null argument");
+    x->ctx->ctx.allreduce_sum(x->buf.p, x->n);
+  });
+}
 int mgb_all_isfinite(mgb_vec x, int* out) {
   return guard([&] {
     need(x && out, "null argument");
@@ -487,6 +516,14 @@ int mgb_amg_dims(mgb_amg a, int* n, int* S, int* K, int* L, int* nY) {
     if (K) *K = a->amg->K();
     if (L) *L = a->amg->L();
     if (nY) *nY = a->amg->params().nY();
+  });
+}
+int mgb_amg_local_rows(mgb_amg a, int* n_global, int* row0, int* n_local) {
+  return guard([&] {
+    need(a, "null amg");
+    if (n_global) *n_global = a->amg->n_global();
+    if (row0) *row0 = a->amg->row0();
+    if (n_local) *n_local = a->amg->n();
   });
 }
 int mgb_amg_level_size(mgb_amg a, int level, int* N, int* nnz_lower) {
@@ -679,6 +716,35 @@ int mgb_plan_eval_host(mgb_plan p, const double* Y, double* lower_vals) {
   return guard([&] {
     need(p && Y && lower_vals, "null argument");
     spmv_host(p->plan.T, Y, lower_vals);
+  });
+}
+
+int mgb_plan_shard(mgb_plan p, int S, int K, int rank, int world, int block, mgb_plan* out, int* r0, int* r1) {
+  return guard([&] {
+    need(p && out && r0 && r1, "plan_shard: null argument");
+    shard_rows(rank, world, p->n, block, r0, r1);
+    auto* q = new mgb_plan_s;
+    try {
+      q->plan = shard_level_plan(p->plan, p->n, S, K, p->nY, *r0, *r1);
+      q->n = *r1 - *r0;
+      q->nY = p->nY;
+    } catch (...) {
+      delete q;
+      throw;
+    }
+    *out = q;
+  });
+}
+int mgb_plan_apply_B_host(mgb_plan p, const double* s, double* Bs) {
+  return guard([&] {
+    need(p && s && Bs, "null argument");
+    spmv_host(p->plan.B, s, Bs);
+  });
+}
+int mgb_plan_apply_BT_host(mgb_plan p, const double* v, double* g) {
+  return guard([&] {
+    need(p && v && g, "null argument");
+    spmv_host(p->plan.BT, v, g);
   });
 }
 

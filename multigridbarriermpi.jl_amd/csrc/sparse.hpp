@@ -153,6 +153,51 @@ inline Csr blockdiag(const std::vector<const Csr*>& blocks) {
   return C;
 }
 
+// rows [r0, r1) of A (row-block shard)
+inline Csr row_block(const Csr& A, int r0, int r1) {
+  if (r0 < 0 || r1 > A.rows || r0 > r1) throw std::runtime_error("row_block: bad range");
+  Csr B(r1 - r0, A.cols);
+  const int b = A.rowptr[r0], e = A.rowptr[r1];
+  B.colidx.assign(A.colidx.begin() + b, A.colidx.begin() + e);
+  B.vals.assign(A.vals.begin() + b, A.vals.begin() + e);
+  for (int r = r0; r <= r1; ++r) B.rowptr[r - r0] = A.rowptr[r] - b;
+  return B;
+}
+
+// rows picked by `pick` (new row i = old row pick[i])
+inline Csr row_select(const Csr& A, const std::vector<int>& pick) {
+  Csr B((int)pick.size(), A.cols);
+  for (size_t i = 0; i < pick.size(); ++i) {
+    const int r = pick[i];
+    if (r < 0 || r >= A.rows) throw std::runtime_error("row_select: row out of range");
+    B.colidx.insert(B.colidx.end(), A.colidx.begin() + A.rowptr[r], A.colidx.begin() + A.rowptr[r + 1]);
+    B.vals.insert(B.vals.end(), A.vals.begin() + A.rowptr[r], A.vals.begin() + A.rowptr[r + 1]);
+    B.rowptr[i + 1] = (int)B.colidx.size();
+  }
+  return B;
+}
+
+// columns renumbered by map[old] (-1 = not in this shard): entries of dropped columns are removed, or, with
+// `strict`, rejected (an operator that couples rows of different shards cannot be row-block sharded).
+// The map must be increasing on the kept columns, so rows stay sorted.
+inline Csr col_remap(const Csr& A, const std::vector<int>& map, int newcols, bool strict) {
+  if ((int)map.size() != A.cols) throw std::runtime_error("col_remap: map size mismatch");
+  Csr B(A.rows, newcols);
+  for (int r = 0; r < A.rows; ++r) {
+    for (int k = A.rowptr[r]; k < A.rowptr[r + 1]; ++k) {
+      const int c = map[A.colidx[k]];
+      if (c < 0) {
+        if (strict) throw std::runtime_error("col_remap: entry couples two shards (operator is not element-local)");
+        continue;
+      }
+      B.colidx.push_back(c);
+      B.vals.push_back(A.vals[k]);
+    }
+    B.rowptr[r + 1] = (int)B.colidx.size();
+  }
+  return B;
+}
+
 inline void spmv_host(const Csr& A, const double* x, double* y) {
   for (int r = 0; r < A.rows; ++r) {
     double s = 0;

@@ -1,0 +1,205 @@
+"""Row-block sharding (reference: HPCSparseArrays row partition + MPI, src:216-221, 259-338).
+
+CPU part (world_size-2 gloo): the host-only shard of a level plan through the C ABI -- each rank applies ITS
+rows of B, ITS columns of BT and T, the ranks' contributions are summed with gloo all_reduce and must equal
+the unsharded products (that is exactly what the GPU path does with the gradient and the Hessian values).
+GPU part: two processes on the one GPU of the test box run the complete sharded solve, allreduce staged
+through the host with gloo (RCCL refuses two ranks on one device), and must land on the unsharded solution."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import mgb_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _full_plan(kind, L, level):
+    """(geo handle, plan handle, n, S, K, nY, block, N, nnz) of the default problem, host-only."""
+    from mgb_amd import _lib
+    import mgb_amd as M
+    import scipy.sparse as sp
+    call, dptr, iptr, f64, i32 = _lib.call, _lib.dptr, _lib.iptr, _lib.f64, _lib.i32
+    g = getattr(O, kind)(L)
+    dim = g.discretization["dim"]
+    x = f64(g.x.reshape(g.x.shape[0], -1))
+    n = x.shape[0]
+    block = {1: 2, 2: 7}[dim]
+    h = C.c_void_p()
+    call("mgb_geo_create", n, x.shape[1], len(g.refine), block, dptr(x), dptr(f64(g.w)), C.byref(h))
+
+    def put(name, S):
+        S = sp.csr_matrix(S)
+        S.sort_indices()
+        call("mgb_geo_set_matrix", h, name.encode(), S.shape[0], S.shape[1], iptr(i32(S.indptr)), iptr(i32(S.indices)),
+             dptr(f64(S.data)))
+
+    for k, S in g.operators.items():
+        put("op:" + k, S)
+    for k, v in g.subspaces.items():
+        for l, S in enumerate(v):
+            put("sub:%s:%d" % (k, l), S)
+    state, D = M.DEFAULT_STATE, M.DEFAULT_D[dim]
+    K = len(D)
+    idx = list(range(K - dim - 1, K))
+    iq = (C.c_int * (len(idx) - 1))(*idx[:-1])
+    p = C.c_void_p()
+    call("mgb_plan_create", h, len(state), _lib.str_array(state), K, _lib.str_array(D), len(idx) - 1, iq, idx[-1], level,
+         C.byref(p))
+    N, nz, nT, nB = (C.c_int() for _ in range(4))
+    call("mgb_plan_sizes", p, C.byref(N), C.byref(nz), C.byref(nT), C.byref(nB))
+    return h, p, n, len(state), K, block, N.value, nz.value
+
+
+def _shard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for pth in (ROOT, os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, pth)
+    import torch
+    import torch.distributed as dist
+    from mgb_amd import _lib
+    call, dptr, f64 = _lib.call, _lib.dptr, _lib.f64
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        out = {}
+        for kind, L in (("fem1d", 3), ("fem2d", 2)):
+            level = L - 1
+            h, p, n, S, K, block, N, nz = _full_plan(kind, L, level)
+            ps = C.c_void_p()
+            r0, r1 = C.c_int(), C.c_int()
+            call("mgb_plan_shard", p, S, K, rank, world, block, C.byref(ps), C.byref(r0), C.byref(r1))
+            nl = r1.value - r0.value
+            assert nl % block == 0 and nl > 0
+            rng = np.random.default_rng(7)                    # same stream on every rank
+            s = rng.standard_normal(N)
+            v = rng.standard_normal(n * K)
+            # B: local rows of the full product
+            Bs_full = np.empty(n * K)
+            call("mgb_plan_apply_B_host", p, dptr(f64(s)), dptr(Bs_full))
+            Bs = np.empty(nl * K)
+            call("mgb_plan_apply_B_host", ps, dptr(f64(s)), dptr(Bs))
+            assert np.array_equal(Bs, Bs_full[r0.value * K:r1.value * K])
+            # BT: contributions of the row blocks sum to the full restriction
+            g_full = np.empty(N)
+            call("mgb_plan_apply_BT_host", p, dptr(f64(v)), dptr(g_full))
+            g = np.empty(N)
+            call("mgb_plan_apply_BT_host", ps, dptr(f64(v[r0.value * K:r1.value * K].copy())), dptr(g))
+            tg = torch.from_numpy(g)
+            dist.all_reduce(tg)
+            assert np.abs(g - g_full).max() <= 1e-13 * np.abs(g_full).max()
+            # T: Hessian values
+            nT = C.c_int()
+            call("mgb_plan_sizes", ps, None, None, C.byref(nT), None)
+            dim = 1 if kind == "fem1d" else 2
+            nY = (dim + 1) * (dim + 2) // 2
+            Y = rng.standard_normal((n, nY))
+            a_full = np.empty(nz)
+            call("mgb_plan_eval_host", p, dptr(f64(Y)), dptr(a_full))
+            a = np.empty(nz)
+            call("mgb_plan_eval_host", ps, dptr(f64(Y[r0.value:r1.value].copy())), dptr(a))
+            ta = torch.from_numpy(a)
+            dist.all_reduce(ta)
+            assert np.abs(a - a_full).max() <= 1e-13 * np.abs(a_full).max()
+            out[kind] = (r0.value, r1.value, n)
+            call("mgb_plan_destroy", ps)
+            call("mgb_plan_destroy", p)
+            call("mgb_geo_destroy", h)
+        q.put((rank, out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(target, world, extra=()):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 7 + 13) % 2000
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=600) for _ in range(world)), key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return out
+
+
+def test_shard_rows_are_element_aligned_and_cover(lib):
+    for n, block, world in ((16, 2, 2), (224, 7, 2), (57344, 7, 8), (224, 7, 3)):
+        prev = 0
+        for r in range(world):
+            r0, r1 = C.c_int(), C.c_int()
+            assert lib.mgb_shard_rows(r, world, n, block, C.byref(r0), C.byref(r1)) == 0
+            assert r0.value == prev and r1.value > r0.value and r0.value % block == 0 and r1.value % block == 0
+            prev = r1.value
+        assert prev == n
+    r0, r1 = C.c_int(), C.c_int()
+    assert lib.mgb_shard_rows(0, 4, 14, 7, C.byref(r0), C.byref(r1)) != 0      # fewer elements than ranks
+
+
+def test_plan_shards_sum_to_the_full_plan_gloo_world2():
+    out = _run(_shard_worker, 2)
+    (ra, a), (rb, b) = out
+    for kind in a:
+        assert a[kind][0] == 0 and a[kind][1] == b[kind][0] and b[kind][1] == a[kind][2]     # a partition
+
+
+def _gpu_worker(rank, world, port, q, kind, L, p):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for pth in (ROOT, os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, pth)
+    import torch.distributed as dist
+    import mgb_amd as M
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        be = M.backend_hip(0)
+        be.set_comm(rank, world, M.torch_allreduce(dist, 0))
+        sol = getattr(M, kind + "_mpi_solve")(L=L, p=p)
+        z = M.mpi_to_native(sol).z
+        q.put((rank, z, np.asarray(sol.SOL_main["its"]), be.comm_stats()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,L,p", [("fem1d", 4, 1.0), ("fem2d", 3, 1.5)])
+def test_sharded_solve_matches_unsharded_two_processes_one_gpu(gpu_required, kind, L, p):
+    import mgb_amd as M
+    ref = M.mpi_to_native(getattr(M, kind + "_mpi_solve")(L=L, p=p)).z
+    out = _run(_gpu_worker, 2, (kind, L, p))
+    (r0, z0, its0, st0), (r1, z1, its1, st1) = out
+    assert np.array_equal(z0, z1) and np.array_equal(its0, its1)          # ranks stay in lock step, bit for bit
+    assert st0["calls"] == st1["calls"] > 0
+    assert np.linalg.norm(z0 - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+def _nccl_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import mgb_amd as M
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        fn = M.torch_allreduce(dist, 0)
+        t = torch.arange(1000, dtype=torch.float64, device="cuda:0")
+        fn(t.data_ptr(), t.numel())                 # RCCL all_reduce in place on a raw device pointer
+        q.put((rank, float(t.sum().item())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_allreduce_callback_on_a_raw_device_pointer(gpu_required):
+    """The production callback (torch.distributed backend "nccl" = RCCL) on the one GPU of the test box: a
+    world of one rank, so the sum is the identity -- what is exercised is the raw-pointer wrapping, the RCCL
+    call and the stream hand-over that bench.py --shard relies on."""
+    out = _run(_nccl_worker, 1)
+    assert out[0][1] == 999 * 1000 / 2
