@@ -81,6 +81,12 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", type=int, default=0)
+    ap.add_argument("--shard", action="store_true",
+                    help="N>1: ONE solve row-block sharded over the ranks (RCCL allreduce of gradient / Hessian values, "
+                         "replicated factorisation; strong scaling) instead of one replica per rank")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N>1 on a single-GPU box: every rank uses cuda:0 and torch.distributed runs on gloo (RCCL refuses "
+                         "two ranks on one device); exercises the multi-rank control flow, not a measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,8 +96,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_one_gpu:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     import numpy as np
     import mgb_amd as M
 
@@ -99,6 +110,9 @@ def main():
         raise SystemExit("bench.py: no HIP device visible (the HIP path has no CPU fallback)")
     dev = local_rank if world > 1 else 0
     backend = M.backend_hip(dev)
+    sharded = bool(args.shard and world > 1)
+    if sharded:      # one solve over all ranks: row blocks + RCCL allreduce
+        backend.set_comm(rank, world, M.torch_allreduce(dist, dev))
 
     # ---- setup (untimed): geometry upload + AMG hierarchy resident in HBM
     t_setup = time.time()
@@ -117,7 +131,7 @@ def main():
         return A.solve(verbose=args.verbose)
 
     # preload code objects with a tiny solve (not a warmup step of the workload)
-    small = M.AMG(M.fem2d_mpi(2, backend=backend), p=args.p)
+    small = M.AMG(M.fem2d_mpi(3 if sharded else 2, backend=backend), p=args.p)
     xs = small.geometry.x.to_numpy()
     small.set_c(np.vstack([M.DEFAULT_F[2](xi) for xi in xs]))
     small.set_z(np.vstack([M.DEFAULT_G[2](xi) for xi in xs]).reshape(-1, order="F"))
@@ -139,12 +153,13 @@ def main():
     backend.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, dist, "cuda")
+    elapsed = max_over_ranks(elapsed, dist, "cpu" if args.rehearse_one_gpu else "cuda")
     if dist is not None:
         dist.barrier()
 
     newton_steps = int(sum(int(s["its"].sum()) for s in sols))
-    value = whole_job_value(n, newton_steps, world, elapsed)
+    # replicas: every rank solved its own copy; sharded: all ranks worked on ONE solve
+    value = whole_job_value(n, newton_steps, 1 if sharded else world, elapsed)
     if rank == 0:
         last = sols[-1]
         kern = {}
@@ -179,10 +194,13 @@ def main():
         out = {
             "metric": "fem2d p-Laplace DoF/s per Newton step", "value": value, "unit": "DoF/s per Newton step",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" + (" (one-GPU rehearsal over gloo: not a measurement)" if args.rehearse_one_gpu else ""),
             "config": {"workload": "fem2d p-Laplace L=%d p=%g (n=%d rows, N_L=%d Newton unknowns), amgb main phase, "
                                    "tol=sqrt(eps)" % (args.L, args.p, n, NL),
-                       "parallelism": "single GPU" if world == 1 else "replicas x%d (not sharded)" % world},
+                       "parallelism": "single GPU" if world == 1 else
+                       ("row-block sharded x%d (RCCL allreduce of gradient + Hessian values, replicated factorisation)"
+                        % world if sharded else "replicas x%d (not sharded)" % world)},
             "total_solve_s": elapsed / args.steps, "newton_steps_per_solve": newton_steps / args.steps,
             "linear_solver": "gpu multifrontal Cholesky (csrc/gpuchol.hip)",
             "linear_solve_s_per_solve": sum(s["time_factor"] for s in sols) / args.steps,
@@ -191,6 +209,8 @@ def main():
             "setup_s": t_setup, "t_final": float(last["ts"][-1]), "c_dot_Dz_final": float(last["c_dot_Dz"][-1]),
             "roofline": roofline,
         }
+        if sharded:
+            out["allreduce"] = backend.comm_stats()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.L, args.p, args.cpu_budget)
         print(json.dumps(out))
