@@ -4,8 +4,9 @@
 A "step" is one full `fem2d_mpi_solve`-equivalent main phase (amgb: t-continuation x level loop x
 Newton) on a geometry + AMG hierarchy already resident in HBM.  value = n * (Newton steps) * K /
 time  ("DoF/s per Newton step", BASELINE.md: DoF := n = rows of x, steps := sum(SOL_main.its)).
-N>1: one process per GPU (torch.distributed over RCCL), each rank solves its own replica of the
-workload this round ("replicas only": the row-block sharded path is not built yet).
+N>1: one process per GPU (torch.distributed over RCCL).  Default: each rank solves its own replica of the
+workload (weak scaling, whole-job value); --shard: ONE solve row-block sharded over the ranks with RCCL
+allreduce of the gradient / Hessian values and a replicated factorisation (strong scaling).
 
 One JSON line on rank 0.  Extra objects: `roofline` (dominant HIP kernel, HIP-event timed inside the
 solve on the library's own stream) and `cpu_baseline` (the numpy/scipy oracle timed on the host)."""
@@ -186,7 +187,7 @@ def main():
                         avg_launch_us=1e3 * kd["ms"] / max(kd["launches"], 1), launches_timed=kd["launches"],
                         algorithmic_bytes_per_launch=kd["bytes"] / max(kd["launches"], 1),
                         note="latency-bound at this size: every working set is L2/Infinity-Cache resident and the "
-                             "factorisation is a dependent chain of ~150 short launches (DESIGN.md section 5)",
+                             "factorisation + solve is a dependent chain of 83 short launches (DESIGN.md sections 4b, 5)",
                         all_kernels={k: dict(gbs=v["bytes"] / max(v["ms"], 1e-12) / 1e6,
                                              avg_us=1e3 * v["ms"] / max(v["launches"], 1), launches_timed=v["launches"],
                                              est_total_s=est[k] / 1e3 / args.steps)
