@@ -290,6 +290,7 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
   if (P.K != (int)spec.D.size()) throw std::runtime_error("amg: barrier K != number of D rows");
   if (P.ncones < 1 || P.ncones > 2) throw std::runtime_error("amg: barrier supports 1 or 2 cones");
+  if (P.K > 8) throw std::runtime_error("amg: the barrier kernels support at most 8 rows of D");
   for (int ci = 0; ci < P.ncones; ++ci) {
     const ConeSpec& S = P.cone[ci];
     if (S.nq < 1 || S.nq > 3) throw std::runtime_error("amg: barrier supports 1..3 gradient components");
@@ -354,8 +355,6 @@ Amg::Level& Amg::level(int l) {
   lv.B.upload(lv.plan.B);
   lv.BT.upload(lv.plan.BT);
   lv.T.upload(lv.plan.T);
-  lv.chol.analyze(lv.plan.Apat, lv.plan.coords.data(), geo_.dim);
-  lv.gchol.build(lv.chol);
   const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
   lv.s.alloc(N);
   lv.s_trial.alloc(N);
@@ -370,6 +369,16 @@ Amg::Level& Amg::level(int l) {
   lv.h_s.alloc(N);
   lv.built = true;
   return lv;
+}
+
+// the factorisation (symbolic analysis + device schedule, 230 MB of fronts at fem2d L=7) is built on first solve,
+// so that kernel-only uses of a level (time_kernels on a large mesh, f0/f1/f2 probes) do not pay for it
+void Amg::ensure_chol(Level& lv) {
+  if (lv.chol_built) return;
+  hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
+  lv.chol.analyze(lv.plan.Apat, lv.plan.coords.data(), geo_.dim);
+  lv.gchol.build(lv.chol);
+  lv.chol_built = true;
 }
 
 const LevelPlan& Amg::plan(int l) { return level(l).plan; }
@@ -503,6 +512,7 @@ double Amg::dev_f1(Level& lv, const double* s_dev, double t, bool reuse_dz, doub
 bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st, double* inc) {
   (void)t;
   const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
+  ensure_chol(lv);
   dev_apply(lv, s_dev);
   timer_.begin(ctx_.stream, KC_F2, (double)n_ * (P_.K + 1 + P_.nY()) * 8);
   launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p);
@@ -823,6 +833,7 @@ void Amg::apply_D(int l, const double* s_host, double* Dz_host) {
 
 bool Amg::solve_device(int l, const double* avals, const double* g, double* nstep) {
   Level& lv = level(l);
+  ensure_chol(lv);
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   lv.avals.upload(avals, lv.plan.Apat.nnz());
   lv.g_trial.upload(g, lv.plan.N);
@@ -835,6 +846,7 @@ bool Amg::solve_device(int l, const double* avals, const double* g, double* nste
 
 bool Amg::solve_host(int l, const double* avals, const double* g, double* nstep) {
   Level& lv = level(l);
+  ensure_chol(lv);
   if (!lv.chol.factor(avals)) return false;
   std::copy(g, g + lv.plan.N, nstep);
   lv.chol.solve(nstep);

@@ -224,7 +224,7 @@ class Amg {
 
  private:
   struct Level {
-    bool built = false;
+    bool built = false, chol_built = false;
     LevelPlan plan;
     DevCsrOwned R, B, BT, T;
     MfChol chol;      // symbolic structure (+ host numeric path)
@@ -237,6 +237,7 @@ class Amg {
     bool converged = false;
   };
   Level& level(int l);            // lazily built
+  void ensure_chol(Level& lv);    // factorisation structures, built on first solve
   void refresh_dz0();
   void dev_apply(Level& lv, const double* s_dev);                 // Dz = Dz0 + B s
   double dev_f0(Level& lv, const double* s_dev, double t, double* parts, const double* phi_ref, double* phi_out);

@@ -30,6 +30,7 @@ inline int grid_for(long long work_items) {
 // G lanes cooperate on one row: lane j reads nonzero j, j+G, ... (coalesced across the group and,
 // because consecutive rows are adjacent in CSR storage, across the 64/G rows of a wave); the
 // G partial sums are combined with a fixed-order shuffle tree -> bitwise reproducible.
+constexpr int kSpmvU = 2;   // rows in flight per lane group (memory-level parallelism of the dependent rowptr -> nnz -> x chain)
 template <int G>
 __global__ __launch_bounds__(kBlock) void spmv_kernel(int rows, const int* __restrict__ rowptr,
                                                        const int* __restrict__ colidx,
@@ -37,19 +38,48 @@ __global__ __launch_bounds__(kBlock) void spmv_kernel(int rows, const int* __res
                                                        const double* __restrict__ x, const double* y0, double* y) {
   const int lane = threadIdx.x % G;
   const long long stride = (long long)gridDim.x * (kBlock / G);
-  for (long long row = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G; row < rows; row += stride) {
-    const int b = rowptr[row], e = rowptr[row + 1];
-    double acc = 0.0;
-    for (int k = b + lane; k < e; k += G) acc += vals[k] * x[colidx[k]];
+  for (long long row0 = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G; row0 < rows; row0 += kSpmvU * stride) {
+    int b[kSpmvU], e[kSpmvU];
+    double acc[kSpmvU], base[kSpmvU];
 #pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, G);
-    if (lane == 0) y[row] = (y0 ? y0[row] : 0.0) + acc;
+    for (int u = 0; u < kSpmvU; ++u) {
+      const long long row = row0 + u * stride;
+      const bool ok = row < rows;
+      b[u] = ok ? rowptr[row] : 0;
+      e[u] = ok ? rowptr[row + 1] : 0;
+      base[u] = (ok && y0 && lane == 0) ? y0[row] : 0.0;
+      acc[u] = 0.0;
+    }
+    // first G nonzeros of every row: all loads of the U rows are independent and issued together
+    int ci[kSpmvU];
+    double va[kSpmvU];
+#pragma unroll
+    for (int u = 0; u < kSpmvU; ++u) {
+      const int k = b[u] + lane;
+      const bool in = k < e[u];
+      ci[u] = in ? colidx[k] : -1;
+      va[u] = in ? vals[k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kSpmvU; ++u) acc[u] = (ci[u] >= 0) ? va[u] * x[ci[u]] : 0.0;
+    // longer rows: remaining nonzeros
+#pragma unroll
+    for (int u = 0; u < kSpmvU; ++u)
+      for (int k = b[u] + lane + G; k < e[u]; k += G) acc[u] += vals[k] * x[colidx[k]];
+#pragma unroll
+    for (int u = 0; u < kSpmvU; ++u) {
+      double a = acc[u];
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) a += __shfl_down(a, o, G);
+      const long long row = row0 + u * stride;
+      if (lane == 0 && row < rows) y[row] = base[u] + a;
+    }
   }
 }
 
 template <int G>
 void spmv_launch(hipStream_t st, const DevCsr& A, const double* x, const double* y0, double* y) {
-  const int grid = grid_for((long long)A.rows * G);
+  const int grid = grid_for((long long)A.rows * G);     // small problems keep one row per lane group
   hipLaunchKernelGGL(spmv_kernel<G>, dim3(grid), dim3(kBlock), 0, st, A.rows, A.rowptr, A.colidx, A.vals, x, y0, y);
 }
 
@@ -146,29 +176,48 @@ __global__ __launch_bounds__(kBlock) void barrier_f0_kernel(int n, BarrierParams
   }
 }
 
+// register-only helpers: the D-row indices of a cone are run-time data, so rows are picked / updated with
+// unrolled selects instead of dynamically indexed local arrays (which would live in scratch) or global
+// read-modify-writes (which serialise on memory latency)
+constexpr int kMaxK = 8;      // rows of D (capi.cpp rejects larger problems for the barrier kernels)
+
+__device__ inline double pick3(const double (&q)[3], int i) { return i == 0 ? q[0] : (i == 1 ? q[1] : q[2]); }
+
 __global__ __launch_bounds__(kBlock) void barrier_f1_kernel(int n, BarrierParams P, const double* __restrict__ Dz,
                                                              const double* __restrict__ w,
-                                                             const double* __restrict__ c, double t, double* v) {
+                                                             const double* __restrict__ c, double t,
+                                                             double* __restrict__ v) {
   for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < n; q += (long long)gridDim.x * kBlock) {
     const double* dz = Dz + q * P.K;
     const double* cq = c + q * P.K;
-    double* vq = v + q * P.K;
     const double wq = w[q];
-    for (int j = 0; j < P.K; ++j) vq[j] = wq * (t * cq[j]);
+    double vr[kMaxK];
+#pragma unroll
+    for (int j = 0; j < kMaxK; ++j) vr[j] = (j < P.K) ? wq * (t * cq[j]) : 0.0;
     for (int ci = 0; ci < P.ncones; ++ci) {
       const ConeSpec& S = P.cone[ci];
       Cone k = load_cone(S, dz);
       const double ds = S.a * pow_a(k.s, S.a - 1.0);  // d(s^a)/ds
-      for (int i = 0; i < S.nq; ++i) vq[S.iq[i]] += wq * (2.0 * k.q[i] / k.phi);
-      const double gs = wq * (-ds / k.phi - S.mu / k.s);
-      vq[S.is] += gs;
-      if (S.is2 >= 0) vq[S.is2] += gs;
+      const double gs = wq * (-ds / k.phi - S.mu / k.s);      // same expressions as the oracle (divisions kept)
+#pragma unroll
+      for (int j = 0; j < kMaxK; ++j) {
+        double add = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) add += (i < S.nq && S.iq[i] == j) ? wq * (2.0 * k.q[i] / k.phi) : 0.0;
+        add += (S.is == j) ? gs : 0.0;
+        add += (S.is2 == j) ? gs : 0.0;
+        vr[j] += add;
+      }
     }
+    double* vq = v + q * P.K;
+#pragma unroll
+    for (int j = 0; j < kMaxK; ++j)
+      if (j < P.K) vq[j] = vr[j];
   }
 }
 
 __global__ __launch_bounds__(kBlock) void barrier_f2_kernel(int n, BarrierParams P, const double* __restrict__ Dz,
-                                                             const double* __restrict__ w, double* Y) {
+                                                             const double* __restrict__ w, double* __restrict__ Y) {
   const int nY = P.nY();
   for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < n; q += (long long)gridDim.x * kBlock) {
     const double* dz = Dz + q * P.K;
@@ -182,16 +231,23 @@ __global__ __launch_bounds__(kBlock) void barrier_f2_kernel(int n, BarrierParams
       const double ds = a * pow_a(k.s, a - 1.0);
       const double dds = (a == 1.0) ? 0.0 : a * (a - 1.0) * pow_a(k.s, a - 2.0);
       const double ip = 1.0 / k.phi, ip2 = ip * ip;
-      // Hessian over (q_0..q_{nq-1}, s); a second slack column repeats the s row/column
-      double h[4][4];
-      for (int i = 0; i < S.nq; ++i) {
-        for (int j = 0; j < S.nq; ++j) h[i][j] = 4.0 * k.q[i] * k.q[j] * ip2 + (i == j ? 2.0 * ip : 0.0);
-        h[i][S.nq] = h[S.nq][i] = -2.0 * k.q[i] * ds * ip2;
-      }
-      h[S.nq][S.nq] = -dds * ip + ds * ds * ip2 + S.mu / (k.s * k.s);
-      const int nact = S.nact();
-      for (int i = 0; i < nact; ++i)
-        for (int j = i; j < nact; ++j) yq[slot++] = wq * h[min(i, S.nq)][min(j, S.nq)];
+      const double hss = -dds * ip + ds * ds * ip2 + S.mu / (k.s * k.s);
+      // Hessian over (q_0..q_{nq-1}, s); a second slack column repeats the s row/column.  Upper triangle,
+      // row-major, of the nact x nact block; entry (i, j) computed from its indices, no local matrix
+      const int nq = S.nq, nact = S.nact();
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          if (i < nact && j >= i && j < nact) {
+            const int ai = min(i, nq), aj = min(j, nq);
+            double h;
+            if (aj < nq) h = 4.0 * pick3(k.q, ai) * pick3(k.q, aj) * ip2 + (ai == aj ? 2.0 * ip : 0.0);
+            else if (ai < nq) h = -2.0 * pick3(k.q, ai) * ds * ip2;
+            else h = hss;
+            yq[slot++] = wq * h;
+          }
+        }
     }
   }
 }

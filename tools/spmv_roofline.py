@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Bandwidth of the barrier / SpMV kernels as a function of mesh size: HIP-event
+timed back-to-back launches on the context stream (Amg::time_kernels), algorithmic bytes as in DESIGN.md
+section 4a.  Shows where the kernels leave the launch-latency regime (L=7: everything cache-resident, ~10 us
+per launch) and what fraction of the 8 TB/s HBM peak they reach on meshes that do not fit the caches.
+usage: python3 tools/spmv_roofline.py [Lmin Lmax]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np          # noqa: E402
+import mgb_amd as M         # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+
+
+def probe(L, p=1.0, reps=20):
+    t0 = time.time()
+    geo = M.fem2d_mpi(L)
+    A = M.AMG(geo, p=p)
+    x = geo.x.to_numpy()
+    n = x.shape[0]
+    c = np.tile(np.asarray(M.DEFAULT_F[2](x[0]), dtype=np.float64), (n, 1))
+    z0 = np.column_stack([x[:, 0] ** 2 + x[:, 1] ** 2, np.full(n, 100.0)]).reshape(-1, order="F")   # DEFAULT_G[2]
+    A.set_c(c)
+    A.set_z(z0)
+    kt = A.time_kernels(A.L - 1, reps)
+    out = dict(L=L, n=n, N=A.level_size(A.L - 1)[0], setup_s=time.time() - t0, kernels={})
+    for k, v in kt.items():
+        gbs = v["bytes"] / max(v["ms"], 1e-9) / 1e6
+        out["kernels"][k] = dict(us=1e3 * v["ms"], MB=v["bytes"] / 1e6, GBs=gbs, frac_hbm=gbs / HBM_PEAK_GBS)
+    return out
+
+
+if __name__ == "__main__":
+    lo = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+    hi = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+    for L in range(lo, hi + 1):
+        print(json.dumps(probe(L)), flush=True)
