@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--shard", action="store_true",
                     help="N>1: ONE solve row-block sharded over the ranks (RCCL allreduce of gradient / Hessian values, "
                          "replicated factorisation; strong scaling) instead of one replica per rank")
+    ap.add_argument("--probe-L", type=int, default=9,
+                    help="after the timed region, HIP-event time the barrier / SpMV kernels back to back on this larger "
+                         "mesh (0 = skip): the size at which they leave the launch-latency regime")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N>1 on a single-GPU box: every rank uses cuda:0 and torch.distributed runs on gloo (RCCL refuses "
                          "two ranks on one device); exercises the multi-rank control flow, not a measurement")
@@ -123,6 +126,7 @@ def main():
     z0 = np.vstack([M.DEFAULT_G[2](xi) for xi in x]).reshape(-1, order="F")
     c = np.vstack([M.DEFAULT_F[2](xi) for xi in x])
     A.set_c(c)
+    A.prepare()                  # operators, Hessian plan, factorisation structures: setup, not solve
     t_setup = time.time() - t_setup
     n = A.n
     NL = A.level_size(A.L - 1)[0]
@@ -212,6 +216,12 @@ def main():
         }
         if sharded:
             out["allreduce"] = backend.comm_stats()
+        if args.probe_L > 0 and not sharded:
+            # secondary evidence for the bandwidth-shaped kernels: same kernels, back-to-back
+            # launches, on the workload mesh (cache resident, launch bound) and on a mesh that exceeds L2
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import spmv_roofline
+            out["kernel_bandwidth_probe"] = [spmv_roofline.probe(L, args.p) for L in sorted({args.L, args.probe_L})]
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.L, args.p, args.cpu_budget)
         print(json.dumps(out))

@@ -110,6 +110,10 @@ int mgb_amg_create_cones(mgb_ctx ctx, mgb_geo g, int S, const char* const* state
 int mgb_amg_destroy(mgb_amg a);
 int mgb_amg_dims(mgb_amg a, int* n, int* S, int* K, int* L, int* nY);   /* n = LOCAL rows on a sharded context */
 int mgb_amg_local_rows(mgb_amg a, int* n_global, int* row0, int* n_local);
+/* levels (operators, Hessian plan) are built on first use and the factorisation structures on the first solve;
+ * mgb_amg_prepare builds both now for `level` (-1: every level the current schedule visits), so that the next
+ * mgb_amg_solve is pure compute */
+int mgb_amg_prepare(mgb_amg a, int level);
 int mgb_amg_level_size(mgb_amg a, int level, int* N, int* nnz_lower);
 int mgb_amg_hessian_pattern(mgb_amg a, int level, int32_t* rowptr, int32_t* colidx);  /* lower triangle of R'HR */
 int mgb_amg_set_c(mgb_amg a, const double* c);     /* n x K row-major cost (f_grid) */

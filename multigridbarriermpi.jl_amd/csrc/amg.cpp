@@ -383,6 +383,14 @@ void Amg::ensure_chol(Level& lv) {
 
 const LevelPlan& Amg::plan(int l) { return level(l).plan; }
 
+void Amg::prepare(int l) {
+  const int L = (int)levels_.size();
+  for (int J = (l >= 0 ? l : (schedule_all_ ? 0 : L - 1)); J <= (l >= 0 ? l : L - 1); ++J) {
+    Level& lv = level(J);
+    if (lv.plan.N > 0) ensure_chol(lv);
+  }
+}
+
 // c, z arrive / leave in the GLOBAL layout on every rank; a sharded Amg keeps its own rows
 void Amg::set_c(const double* c_host) { c_.upload(c_host + (size_t)r0_ * P_.K, (size_t)n_ * P_.K); }
 

@@ -191,6 +191,9 @@ class Amg {
   int L() const { return (int)levels_.size(); }
   int level_size(int l) const { return levels_[l]->plan.N; }
   const LevelPlan& plan(int l);   // builds the level on first use
+  // build everything a solve needs at level l (-1: every level of the current schedule), incl. the factorisation
+  // structures, so that the next solve() is pure compute
+  void prepare(int l);
   const BarrierParams& params() const { return P_; }
 
   // problem data: c is n x K row-major, z is the S*n vector [u; s]

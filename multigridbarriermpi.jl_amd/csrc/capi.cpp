@@ -526,6 +526,12 @@ int mgb_amg_local_rows(mgb_amg a, int* n_global, int* row0, int* n_local) {
     if (n_local) *n_local = a->amg->n();
   });
 }
+int mgb_amg_prepare(mgb_amg a, int level) {
+  return guard([&] {
+    need(a && level >= -1 && level < a->amg->L(), "level out of range");
+    a->amg->prepare(level);
+  });
+}
 int mgb_amg_level_size(mgb_amg a, int level, int* N, int* nnz_lower) {
   return guard([&] {
     need(a && level >= 0 && level < a->amg->L(), "level out of range");

@@ -133,7 +133,7 @@ __device__ void factor_diag_block(const double* D, int kw, double* Lo, double* l
   }
 }
 
-// Start of a height: workgroup = 32 columns of one front, in gather form.  (1) every lower entry (and the
+// Start of a height: workgroup = 32 columns x 256 rows of one front, in gather form.  (1) every lower entry (and the
 // right-hand-side row nf) of the columns is WRITTEN as child0 + child1 contribution (or 0), found through the
 // per-child inverse index maps (parent row -> child boundary row, -1 if absent): no read-modify-write chains,
 // the loads of all 32 columns are issued (branch-free) before their stores; (2) the assembled matrix entries and the right-hand side
@@ -177,7 +177,13 @@ __global__ __launch_bounds__(TB) void front_start_kernel(const GNode* __restrict
   STAMP(1);
   const double* __restrict__ B0 = fronts_ro + boff[0];
   const double* __restrict__ B1 = fronts_ro + boff[1];
-  for (int i = c0 + tid; i <= nf; i += TB) {
+  const int i = c0 + job.rb * TB + tid;        // one row per thread: the workgroup owns rows [c0 + 256 rb, +256)
+  if (i <= nf && !has[0] && !has[1]) {      // leaf front (workgroup-uniform): nothing to gather, just clear
+    const int cend = min(c1, i + 1);
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      if (c0 + q < cend) F[(long long)ld * (c0 + q) + i] = 0.0;
+  } else if (i <= nf) {
     const int ra0 = has[0] ? inv0[i] : -1, ra1 = has[1] ? inv1[i] : -1;
     const int cend = min(c1, i + 1);       // lower triangle: columns c <= i (row nf: every column)
     double v[PB];
@@ -197,8 +203,9 @@ __global__ __launch_bounds__(TB) void front_start_kernel(const GNode* __restrict
   __syncthreads();
   STAMP(2);
   for (int k = job.a0 + tid; k < job.a1; k += TB) F[asm_pos[k]] += vals[asm_src[k]];
-  for (int c = c0 + tid; c < min(c1, ns); c += TB) F[(long long)ld * c + nf] += b[perm[nd.first + c]];
-  if (job.chunk == 0 && ns > 0) {
+  if (c0 + job.rb * TB <= nf && nf < c0 + (job.rb + 1) * TB)      // this workgroup owns the right-hand-side row
+    for (int c = c0 + tid; c < min(c1, ns); c += TB) F[(long long)ld * c + nf] += b[perm[nd.first + c]];
+  if (job.chunk == 0 && job.rb == 0 && ns > 0) {
     __syncthreads();
     STAMP(3);
     const int kw = min(PB, ns);
@@ -517,29 +524,42 @@ void GpuChol::build(const MfChol& sym) {
     }
   }
   nheights_ = nnodes_ ? *std::max_element(height.begin(), height.end()) + 1 : 0;
-  // assembly map, per node sorted by destination column, positions in the (nf+1)-leading-dimension layout
+  // assembly map, per node sorted by the front_start job (32-column chunk, 256-row block counted from the chunk's
+  // first row) that owns the destination; positions in the (nf+1)-leading-dimension layout
   std::vector<int> asrc, apos;
-  std::vector<std::vector<int>> acol_ofs(nnodes_);     // per node: offsets into asrc per 32-column chunk (+1)
+  std::vector<std::vector<StartJob>> sjobs(nnodes_);
   for (int t = 0; t < nnodes_; ++t) {
     const int nf = nodes[t].nf, ld = nf + 1;
     const size_t m = sym.a_idx_[t].size();
+    const int nch = (nf + PB - 1) / PB;
+    auto key = [&](int e) {
+      const int pos = sym.a_pos_[t][e], col = pos / nf, row = pos % nf, ch = col / PB;
+      return (long long)ch * 65536 + (row - ch * PB) / TB;
+    };
     std::vector<int> ord(m);
     std::iota(ord.begin(), ord.end(), 0);
-    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return sym.a_pos_[t][a] / nf < sym.a_pos_[t][b] / nf; });
-    const int nch = (nf + PB - 1) / PB;
-    acol_ofs[t].assign(nch + 1, 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key(a) < key(b); });
     size_t q = 0;
     for (int ch = 0; ch < nch; ++ch) {
-      acol_ofs[t][ch] = (int)asrc.size();
-      while (q < m && sym.a_pos_[t][ord[q]] / nf < (ch + 1) * PB) {
-        const int pos = sym.a_pos_[t][ord[q]], col = pos / nf, row = pos % nf;
-        if (row < col) throw std::runtime_error("gpuchol: assembly entry above the diagonal");
-        asrc.push_back(sym.a_idx_[t][ord[q]]);
-        apos.push_back(ld * col + row);
-        ++q;
+      const int nrb = (nf + 1 - ch * PB + TB - 1) / TB;      // rows ch*32 .. nf inclusive
+      if (nrb > 65535) throw std::runtime_error("gpuchol: front too large for the start-job key");
+      for (int rb = 0; rb < nrb; ++rb) {
+        StartJob j{};
+        j.node = t;
+        j.chunk = ch;
+        j.rb = rb;
+        j.a0 = (int)asrc.size();
+        while (q < m && key(ord[q]) == (long long)ch * 65536 + rb) {
+          const int pos = sym.a_pos_[t][ord[q]], col = pos / nf, row = pos % nf;
+          if (row < col) throw std::runtime_error("gpuchol: assembly entry above the diagonal");
+          asrc.push_back(sym.a_idx_[t][ord[q]]);
+          apos.push_back(ld * col + row);
+          ++q;
+        }
+        j.a1 = (int)asrc.size();
+        sjobs[t].push_back(j);
       }
     }
-    acol_ofs[t][nch] = (int)asrc.size();
     if (q != m) throw std::runtime_error("gpuchol: assembly entry outside the front");
   }
   // schedule
@@ -572,22 +592,14 @@ void GpuChol::build(const MfChol& sym) {
     hp.start_bytes = 0;
     for (int t : mine) {
       const GNode& g = nodes[t];
-      const int nch = (g.nf + PB - 1) / PB;
       hp.start_bytes += 0.5 * g.nf * g.nf * 8.0 + (double)sym.a_idx_[t].size() * 20.0;
-      for (int ch = 0; ch < nch; ++ch) {
-        StartJob j{};
-        j.node = t;
-        j.chunk = ch;
-        j.a0 = acol_ofs[t][ch];
-        j.a1 = acol_ofs[t][ch + 1];
-        for (int s = 0; s < 2; ++s) {
-          const int c = g.child[s];
-          if (c < 0 || ch != 0) continue;
-          const double cnb = nodes[c].nf - nodes[c].ns;
-          hp.start_bytes += 0.5 * cnb * cnb * 8.0;     // child entry read (the parent entry write is counted above)
-        }
-        starts.push_back(j);
+      for (int s = 0; s < 2; ++s) {
+        const int c = g.child[s];
+        if (c < 0) continue;
+        const double cnb = nodes[c].nf - nodes[c].ns;
+        hp.start_bytes += 0.5 * cnb * cnb * 8.0;     // child entry read (the parent entry write is counted above)
       }
+      starts.insert(starts.end(), sjobs[t].begin(), sjobs[t].end());
     }
     hp.start.cnt = (int)starts.size() - hp.start.ofs;
     launches_++;

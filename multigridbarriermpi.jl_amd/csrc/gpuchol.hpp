@@ -41,8 +41,8 @@ struct GNode {
   int iofs;           // offset of the two (nf+1)-long inverse extend-add maps (-1: leaf)
 };
 
-struct StartJob {     // one workgroup of front_start: 32 columns of one front
-  int node, chunk;
+struct StartJob {     // one workgroup of front_start: 32 columns x 256 rows (counted from the chunk's first row) of one front
+  int node, chunk, rb;
   int a0, a1;         // range of the (column-sorted) assembly list
 };
 
