@@ -225,11 +225,89 @@ __global__ __launch_bounds__(TB) void front_start_kernel(const GNode* __restrict
 // (rows / columns counted from k1 = end of the panel; rows run to nf INCLUSIVE: the right-hand-side row).
 //   L_I = A[I, panel] * L11^-T, L_J likewise   (64x32 each, re-derived per tile from the stored pivot block)
 //   C[I, J] -= L_I L_J'
-// The tj == 0 tiles store L_I into the upper triangle (L[i][k] at row k, column i).  Tile (0,0) then factors
-// the next 32x32 pivot block out of its own registers, so the next launch can start from it.
+// The tj == 0 tiles store L_I into the upper triangle (L[i][k] at row k, column i).  The first `npiv`
+// workgroups of the launch are pivot workgroups (pivot_path): one per front that has a next panel, they do only
+// what the NEXT launch waits for -- the 32 panel rows, the 32x32 corner of the update and its factorisation.
+// One row x of X L11' = A (A, X: 1 x 32 in registers f) by right-looking substitution against the pivot block
+// Lc (LDS, column-major: Lc[32 j + m] = L[m][j], reciprocal diagonal).  Software pipeline: column j+1 of L11
+// is requested (all its LDS reads in flight) before column j is consumed; the empty asm keeps the compiler
+// from sinking the reads back next to their uses.
+__device__ inline void trsm_row(double (&f)[PB], const double* Lc) {
+  double lc[2][PB];
+#pragma unroll
+  for (int m = 0; m < PB; ++m) lc[0][m] = Lc[m];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    if (j + 1 < PB) {
+#pragma unroll
+      for (int m = (j + 1) & ~1; m < PB; ++m) lc[(j + 1) & 1][m] = Lc[(j + 1) * PB + m];
+    }
+    asm volatile("" ::: "memory");
+    const double fj = f[j] * lc[j & 1][j];          // diagonal slot holds 1 / L[j][j]
+    f[j] = fj;
+#pragma unroll
+    for (int m = j + 1; m < PB; ++m) f[m] = fma(-fj, lc[j & 1][m], f[m]);
+  }
+}
+
+// Critical path of a panel step, run by a dedicated workgroup per front: rows k1..k1+31 of the panel are solved
+// against the current pivot block, the 32x32 corner C[k1:k1+32, k1:k1+32] gets its rank-32 update, and the result
+// -- the next pivot block -- is factored and published.  The regular tile (0,0) of the same launch handles the
+// rest of its 64x64 tile (and the mirrored copy of these rows) but leaves the corner alone; nobody reads the
+// corner again once its factor is stored.
+__device__ inline void pivot_path(const StepTile& t, int p, double* sh, double* fronts,
+                                  const double* __restrict__ linv_ro, double* linv, int* fail, long long* prof) {
+  double* Lc = sh;                     // column-major pivot block of THIS panel
+  double* P = sh + PB * PB;            // solved panel rows, P[r * LP + q]
+  double* D = P + PB * LP;             // updated corner = next pivot block
+  double* Lo = D + PB * LP;            // scratch of the factorisation
+  const int nf = t.nf, ld = nf + 1, k0 = p * PB, kw = min(PB, t.ns - k0), k1 = k0 + kw, kw2 = min(PB, t.ns - k1);
+  double* F = fronts + t.off;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < PB * PB; idx += TB) Lc[idx] = linv_ro[t.loff + PB * PB + idx];
+  const int ci = tid & 31, cj = tid >> 5;       // corner entry (ci, cj + 8 b), b = 0..3
+  double c[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int j = cj + 8 * b;
+    c[b] = (j <= ci && ci < kw2) ? F[(long long)ld * (k1 + j) + k1 + ci] : 0.0;
+  }
+  double f[PB];
+  if (tid < PB) {
+#pragma unroll
+    for (int m = 0; m < PB; ++m) f[m] = (m < kw && tid < kw2) ? F[(long long)ld * (k0 + m) + k1 + tid] : 0.0;
+  }
+  __syncthreads();
+  STAMP(1);
+  if (tid < PB) {
+    trsm_row(f, Lc);
+#pragma unroll
+    for (int m = 0; m < PB; ++m) P[tid * LP + m] = f[m];
+  }
+  __syncthreads();
+  STAMP(2);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int j = cj + 8 * b;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < PB; q += 2) {
+      a0 = fma(P[ci * LP + q], P[j * LP + q], a0);
+      a1 = fma(P[ci * LP + q + 1], P[j * LP + q + 1], a1);
+    }
+    D[ci * LP + j] = c[b] - (a0 + a1);
+  }
+  STAMP(3);
+  __syncthreads();
+  STAMP(4);
+  STAMP(5);
+  factor_diag_block(D, kw2, Lo, linv + t.loff + 2 * PB * PB, fail, prof);
+  STAMP(7);
+}
+
 __device__ inline int tile_pos(int r) { return 4 * (r & 15) + (r >> 4); }   // LDS slot of tile row r (see below)
 
-__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void front_step_kernel(const StepTile* __restrict__ tiles, int p, double* fronts,
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void front_step_kernel(const StepTile* __restrict__ tiles, int p, int npiv, double* fronts,
                                                          const double* __restrict__ linv_ro, double* linv, int* fail,
                                                          long long* prof) {
   // panel rows of the tile, transposed: AT[q * 64 + tile_pos(r)] = (row r, panel column q).  The slot
@@ -241,6 +319,10 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   double* Lc = sh + 2 * PB * TS;      // column-major pivot block: Lc[32 j + m] = L[m][j]
   STAMP(0);
   const StepTile t = tiles[blockIdx.x];
+  if ((int)blockIdx.x < npiv) {      // workgroup-uniform: the dedicated pivot workgroup of one front
+    pivot_path(t, p, sh, fronts, linv_ro, linv, fail, prof);
+    return;
+  }
   const int nf = t.nf, ld = nf + 1, k0 = p * PB, kw = min(PB, t.ns - k0), k1 = k0 + kw;
   double* F = fronts + t.off;
   const int r0 = k1 + TS * t.ti, c0 = k1 + TS * t.tj;
@@ -263,23 +345,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     double f[PB];
 #pragma unroll
     for (int m = 0; m < PB; ++m) f[m] = A[m * TS];
-    // software pipeline: column j+1 of L11 is requested (all its LDS reads in flight) before column j is
-    // consumed; the empty asm keeps the compiler from sinking the reads back next to their uses
-    double lc[2][PB];
-#pragma unroll
-    for (int m = 0; m < PB; ++m) lc[0][m] = Lc[m];
-#pragma unroll
-    for (int j = 0; j < PB; ++j) {
-      if (j + 1 < PB) {
-#pragma unroll
-        for (int m = (j + 1) & ~1; m < PB; ++m) lc[(j + 1) & 1][m] = Lc[(j + 1) * PB + m];
-      }
-      asm volatile("" ::: "memory");
-      const double fj = f[j] * lc[j & 1][j];          // diagonal slot holds 1 / L[j][j]
-      f[j] = fj;
-#pragma unroll
-      for (int m = j + 1; m < PB; ++m) f[m] = fma(-fj, lc[j & 1][m], f[m]);
-    }
+    trsm_row(f, Lc);
 #pragma unroll
     for (int m = 0; m < PB; ++m) A[m * TS] = f[m];
     if (t.tj == 0 && tid < TS && r0 + r <= nf) {         // finished rows of L go to the mirrored (upper) half
@@ -291,14 +357,16 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   }
   __syncthreads();
   STAMP(2);
-  // the C micro-tile (4x4 per thread) is requested here so that its latency hides behind the rank-32 update
+  // the C micro-tile (4x4 per thread) is requested here so that its latency hides behind the rank-32 update;
+  // the 32x32 corner that becomes the next pivot block belongs to the pivot workgroup
+  const int kc = (t.ti == 0 && t.tj == 0) ? min(t.ns, k1 + PB) : 0;      // rows/columns < kc: the next pivot block
   double c[4][4];
 #pragma unroll
   for (int bq = 0; bq < 4; ++bq)
 #pragma unroll
     for (int aq = 0; aq < 4; ++aq) {
       const int i = r0 + tx + 16 * aq, j = c0 + ty + 16 * bq;
-      c[aq][bq] = (i <= nf && j < nf && i >= j) ? F[(long long)ld * j + i] : 0.0;
+      c[aq][bq] = (i <= nf && j < nf && i >= j && !(i < kc && j < kc)) ? F[(long long)ld * j + i] : 0.0;
     }
   const double* LI = ATI + 4 * tx;
   const double* LJ = (diag ? ATI : ATJ) + 4 * ty;
@@ -323,21 +391,9 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     for (int aq = 0; aq < 4; ++aq) {
       const int i = r0 + tx + 16 * aq, j = c0 + ty + 16 * bq;
       c[aq][bq] -= acc[aq][bq];
-      if (i <= nf && j < nf && i >= j) F[(long long)ld * j + i] = c[aq][bq];
+      if (i <= nf && j < nf && i >= j && !(i < kc && j < kc)) F[(long long)ld * j + i] = c[aq][bq];
     }
   STAMP(3);
-  if (t.ti == 0 && t.tj == 0 && k1 < t.ns) {
-    __syncthreads();
-    STAMP(4);
-    double* D = sh;
-#pragma unroll
-    for (int aq = 0; aq < 2; ++aq)
-#pragma unroll
-      for (int bq = 0; bq < 2; ++bq) D[(tx + 16 * aq) * LP + ty + 16 * bq] = c[aq][bq];
-    __syncthreads();
-    STAMP(5);
-    factor_diag_block(D, min(PB, t.ns - k1), sh + PB * LP, linv + t.loff + 2 * PB * PB, fail, prof);
-  }
   STAMP(7);
 }
 
@@ -608,31 +664,36 @@ void GpuChol::build(const MfChol& sym) {
     for (int p = 0; p < npanel; ++p) {
       Range rt{(int)tiles.size(), 0};
       double bytes = 0;
+      int npiv = 0;
       for (int pass = 0; pass < 2; ++pass)
         for (int t : mine) {
           const GNode& g = nodes[t];
           if (g.ns <= p * PB) continue;
           const int k1 = std::min(g.ns, (p + 1) * PB), kw = k1 - p * PB;
-          const int Tr = (g.nf + 1 - k1 + TS - 1) / TS, Tc = std::max(1, (g.nf - k1 + TS - 1) / TS);
-          if (Tr > 30000) throw std::runtime_error("gpuchol: front too large for tile index");
-          if (pass == 0) {
+          StepTile st{};
+          st.off = g.off;
+          st.loff = g.loff + (long long)p * 2 * PB * PB;
+          st.nf = g.nf;
+          st.ns = g.ns;
+          if (pass == 0) {      // pivot workgroups first: they are the critical path of the next launch
+            if (k1 < g.ns) {
+              tiles.push_back(st);
+              npiv++;
+            }
             const double tr = g.nf + 1 - k1;
             bytes += tr * kw * 16.0 + 0.5 * tr * tr * 16.0;      // panel read + mirrored write, trailing read + write
+            continue;
           }
+          const int Tr = (g.nf + 1 - k1 + TS - 1) / TS, Tc = std::max(1, (g.nf - k1 + TS - 1) / TS);
+          if (Tr > 30000) throw std::runtime_error("gpuchol: front too large for tile index");
           for (int ti = 0; ti < Tr; ++ti)
             for (int tj = 0; tj <= std::min(ti, Tc - 1); ++tj) {
-              const bool first = (ti == 0 && tj == 0);
-              if (first != (pass == 0)) continue;
-              StepTile st{};
-              st.off = g.off;
-              st.loff = g.loff + (long long)p * 2 * PB * PB;
-              st.nf = g.nf;
-              st.ns = g.ns;
               st.ti = (short)ti;
               st.tj = (short)tj;
               tiles.push_back(st);
             }
         }
+      hp.step_npiv.push_back(npiv);
       rt.cnt = (int)tiles.size() - rt.ofs;
       hp.step.push_back(rt);
       hp.step_bytes.push_back(bytes);
@@ -705,7 +766,7 @@ void GpuChol::factor_solve(hipStream_t st, const double* d_vals, const double* d
     for (size_t p = 0; p < hp.step.size(); ++p) {
       if (tm) tm->begin(st, KC_CHOL_STEP, hp.step_bytes[p]);
       hipLaunchKernelGGL(front_step_kernel, dim3(hp.step[p].cnt), dim3(TB), 0, st, d_tiles_ + hp.step[p].ofs, (int)p,
-                         d_fronts_, d_linv_, d_linv_, d_fail_, d_prof_ ? d_prof_ + 8 * (nprof++) : nullptr);
+                         hp.step_npiv[p], d_fronts_, d_linv_, d_linv_, d_fail_, d_prof_ ? d_prof_ + 8 * (nprof++) : nullptr);
       if (tm) tm->end(st);
     }
   }

@@ -104,6 +104,7 @@ class GpuChol {
   struct HeightPlan {
     Range nodes, start, rect;
     std::vector<Range> step;
+    std::vector<int> step_npiv;   // leading pivot workgroups of every step launch
     std::vector<double> step_bytes;
     double start_bytes, rect_bytes, tri_bytes;
     int max_nf;
