@@ -523,6 +523,7 @@ T* GpuChol::upload(const std::vector<T>& v) {
 }
 
 GpuChol::~GpuChol() {
+  for (GraphEntry& g : graphs_) (void)hipGraphExecDestroy(g.exec);
   for (void* p : allocs_) (void)hipFree(p);
 }
 
@@ -752,8 +753,42 @@ void GpuChol::build(const MfChol& sym) {
   }
 }
 
+// The whole chain is launch-bound (83 dependent launches at fem2d L=7), so it is captured once per
+// (values, rhs, solution) pointer triple into a hipGraph and replayed with ONE host call per Newton step; the
+// event-timed and phase-stamped variants (KernelTimer, MGB_CHOL_PROF) and MGB_CHOL_GRAPH=0 use plain launches.
 void GpuChol::factor_solve(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm) {
   if (n_ == 0) return;
+  static const bool use_graph = [] {
+    const char* e = std::getenv("MGB_CHOL_GRAPH");
+    return !(e && e[0] == '0');
+  }();
+  if (!use_graph || tm || d_prof_) {
+    enqueue(st, d_vals, d_b, d_x, tm);
+    return;
+  }
+  for (const GraphEntry& g : graphs_)
+    if (g.vals == d_vals && g.b == d_b && g.x == d_x) {
+      ck(hipGraphLaunch(g.exec, st), "hipGraphLaunch");
+      return;
+    }
+  hipGraph_t graph = nullptr;
+  ck(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+  try {
+    enqueue(st, d_vals, d_b, d_x, nullptr);
+  } catch (...) {
+    (void)hipStreamEndCapture(st, &graph);
+    if (graph) (void)hipGraphDestroy(graph);
+    throw;
+  }
+  ck(hipStreamEndCapture(st, &graph), "hipStreamEndCapture");
+  GraphEntry ge{d_vals, d_b, d_x, nullptr};
+  ck(hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+  (void)hipGraphDestroy(graph);
+  graphs_.push_back(ge);
+  ck(hipGraphLaunch(ge.exec, st), "hipGraphLaunch");
+}
+
+void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm) {
   ck(hipMemsetAsync(d_fail_, 0, sizeof(int), st), "memset flag");
   int nprof = 0;
   for (int h = 0; h < nheights_; ++h) {

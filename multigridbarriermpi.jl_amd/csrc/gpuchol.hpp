@@ -77,6 +77,14 @@ class GpuChol {
  private:
   template <class T>
   T* upload(const std::vector<T>& v);
+  void enqueue(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* timer);
+  struct GraphEntry {      // captured launch chain for one (values, rhs, solution) pointer triple
+    const double* vals;
+    const double* b;
+    double* x;
+    hipGraphExec_t exec;
+  };
+  std::vector<GraphEntry> graphs_;
   int n_ = 0, nnodes_ = 0, nheights_ = 0, launches_ = 0, max_nf_ = 0;
   long long total_front_ = 0;
   double flops_ = 0;
