@@ -244,24 +244,64 @@ int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const do
       axis = d;
     }
   }
-  const int midp = lo + cnt / 2;
-  std::nth_element(dofs.begin() + lo, dofs.begin() + midp, dofs.begin() + hi, [&](int a, int b) {
-    double ca = coords[(size_t)a * dim + axis], cb = coords[(size_t)b * dim + axis];
+  // Sort along the axis and cut BETWEEN two distinct coordinate values (a straight mesh line: co-located dofs of
+  // different state variables stay together and the cut does not wander through a column of tied coordinates),
+  // trying the few such cuts nearest to the median and both one-sided separators (A-side dofs adjacent to B, or
+  // B-side dofs adjacent to A); the smallest separator wins.  Separator sizes set the number of 32-pivot
+  // panels on the critical path of the device factorisation (gpuchol.hip), so this is worth a few extra passes.
+  auto key = [&](int v) { return coords[(size_t)v * dim + axis]; };
+  std::sort(dofs.begin() + lo, dofs.begin() + hi, [&](int a, int b) {
+    const double ca = key(a), cb = key(b);
     return ca != cb ? ca < cb : a < b;
   });
+  std::vector<int> cand;
+  {
+    const int mid = lo + cnt / 2, wlo = lo + (int)(0.3 * cnt), whi = lo + (int)(0.7 * cnt);
+    for (int step = 0; (int)cand.size() < 4 && (mid - step > wlo || mid + step < whi); ++step) {
+      for (int sgn = -1; sgn <= 1; sgn += 2) {
+        const int bpos = mid + sgn * step;
+        if (step == 0 && sgn == 1) continue;
+        if (bpos <= std::max(lo, wlo) || bpos >= std::min(hi, whi)) continue;
+        if (key(dofs[bpos - 1]) != key(dofs[bpos])) cand.push_back(bpos);
+      }
+    }
+    if (cand.empty()) cand.push_back(mid);
+  }
   const int tagA = next_label++, tagB = next_label++;
+  int midp = cand[0], best_size = -1;
+  bool sep_in_A = true;
+  for (int bpos : cand) {
+    for (int i = lo; i < bpos; ++i) label[dofs[i]] = tagA;
+    for (int i = bpos; i < hi; ++i) label[dofs[i]] = tagB;
+    int sa = 0, sb = 0;
+    for (int i = lo; i < hi; ++i) {
+      const int v = dofs[i], other = (i < bpos) ? tagB : tagA;
+      bool sep = false;
+      for (int k = A.rowptr[v]; k < A.rowptr[v + 1] && !sep; ++k) sep = (label[A.colidx[k]] == other);
+      if (sep) (i < bpos ? sa : sb)++;
+    }
+    const int sz = std::min(sa, sb);
+    if (best_size < 0 || sz < best_size) {
+      best_size = sz;
+      midp = bpos;
+      sep_in_A = sa <= sb;
+    }
+  }
   for (int i = lo; i < midp; ++i) label[dofs[i]] = tagA;
   for (int i = midp; i < hi; ++i) label[dofs[i]] = tagB;
-  // separator = A-side vertices adjacent to B
-  std::vector<int> Ap, S;
-  for (int i = lo; i < midp; ++i) {
+  // Ap / Bv: the two halves without the separator S (taken from one side)
+  std::vector<int> Ap, Bv, S;
+  for (int i = lo; i < hi; ++i) {
     const int v = dofs[i];
+    const bool inA = i < midp;
     bool sep = false;
-    for (int k = A.rowptr[v]; k < A.rowptr[v + 1] && !sep; ++k) sep = (label[A.colidx[k]] == tagB);
-    (sep ? S : Ap).push_back(v);
+    if (inA == sep_in_A) {
+      const int other = inA ? tagB : tagA;
+      for (int k = A.rowptr[v]; k < A.rowptr[v + 1] && !sep; ++k) sep = (label[A.colidx[k]] == other);
+    }
+    (sep ? S : (inA ? Ap : Bv)).push_back(v);
   }
-  if (Ap.empty() || (int)S.size() * 2 > cnt) return make_leaf();  // S empty: disconnected halves, empty separator node
-  std::vector<int> Bv(dofs.begin() + midp, dofs.begin() + hi);
+  if (Ap.empty() || Bv.empty() || (int)S.size() * 2 > cnt) return make_leaf();  // S empty: disconnected halves, empty separator node
   std::copy(Ap.begin(), Ap.end(), dofs.begin() + lo);
   std::copy(Bv.begin(), Bv.end(), dofs.begin() + lo + Ap.size());
   std::copy(S.begin(), S.end(), dofs.begin() + lo + Ap.size() + Bv.size());
