@@ -139,7 +139,7 @@ __device__ void factor_diag_block(const double* D, int kw, double* Lo, double* l
 // the loads of all 32 columns are issued (branch-free) before their stores; (2) the assembled matrix entries and the right-hand side
 // are added; (3) the workgroup of columns 0..31 factors the first pivot block.  Every parent entry belongs to
 // exactly one workgroup and the order of the additions is fixed.
-__global__ __launch_bounds__(TB) void front_start_kernel(const GNode* __restrict__ nodes, const StartJob* __restrict__ jobs,
+__global__ __launch_bounds__(TB, 3) void front_start_kernel(const GNode* __restrict__ nodes, const StartJob* __restrict__ jobs,
                                                           const int* __restrict__ pinv, const int* __restrict__ asm_src,
                                                           const int* __restrict__ asm_pos, const double* __restrict__ vals,
                                                           const int* __restrict__ perm, const double* __restrict__ b,

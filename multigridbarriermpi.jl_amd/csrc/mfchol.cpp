@@ -318,6 +318,7 @@ int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const do
 }
 
 void MfChol::analyze(const Csr& Ain, const double* coords, int dim, int leaf_size) {
+  if (const char* e = std::getenv("MGB_LEAF")) leaf_size = std::max(8, std::atoi(e));      // tuning knob
   if (Ain.rows != Ain.cols) throw std::runtime_error("MfChol: matrix not square");
   n_ = Ain.rows;
   // symmetric adjacency (pattern + transpose) for ordering and the symbolic phase
