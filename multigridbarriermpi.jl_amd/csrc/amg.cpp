@@ -432,7 +432,7 @@ KernelTimer::~KernelTimer() {
 }
 
 void KernelTimer::begin(hipStream_t st, int cls, double bytes) {
-  if (!on_) return;
+  if (!on_ || !sampling_) return;
   if (free_.empty()) {
     Pair p{};
     hip_check(hipEventCreate(&p.a), "hipEventCreate");
@@ -517,8 +517,22 @@ double Amg::dev_f1(Level& lv, const double* s_dev, double t, bool reuse_dz, doub
 
 // Hessian at s, Newton direction nstep = H \ g (device); returns false if H is not numerically SPD.
 // inc = <g, nstep>.
-bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st, double* inc) {
-  (void)t;
+static const double kBeta = 0.5, kArmijo = 0.1, kMinStep = 1e-8;      // oracle BETA, ARMIJO, MIN_STEP
+
+// enqueue (no host sync): T.s = s - step * nstep, f0 there -> host slot h_scal_[4 + 2 slot .. +1]
+void Amg::enqueue_trial(Level& lv, Trial& T, double step, int slot) {
+  launch_waxpby(ctx_.stream, lv.plan.N, lv.s.p, -step, lv.nstep.p, T.s);
+  dev_apply(lv, T.s);
+  double* out = scal_.p + 4 + 2 * slot;
+  timer_.begin(ctx_.stream, KC_F0, (double)n_ * (2 * P_.K + 3) * 8);
+  launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, phi_cur_.p, kFracToBoundary, T.phi, partials_.p, out);
+  timer_.end(ctx_.stream);
+  ctx_.allreduce_sum(out, 2);
+  hip_check(hipMemcpyAsync(h_scal_.p + 4 + 2 * slot, out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H trial");
+  T.step = step;
+}
+
+bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st, double* inc, Trial* spec) {
   const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
   ensure_chol(lv);
   dev_apply(lv, s_dev);
@@ -531,6 +545,8 @@ bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st,
   ctx_.allreduce_sum(lv.avals.p, nnzA);      // sharded: every rank then factors the same replicated matrix
   st.n_f2++;
   st.n_factor++;
+  // event pairs cost ~14 % of a solve when every launch is bracketed: time every 8th Newton step only
+  timer_.sample((st.n_factor % 8) == 1);
   if (!host_solve_) {
     // device multifrontal factorisation + sweeps: nothing but two scalars and a flag cross PCIe
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -539,13 +555,23 @@ bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st,
       hip_check(hipEventCreate(&e1), "event");
       hip_check(hipEventRecord(e0, ctx_.stream), "record");
     }
-    KernelTimer* tm = (live_ && (st.n_factor % 8) == 1) ? &timer_ : nullptr;
+    KernelTimer* tm = (live_ && timer_.sampling()) ? &timer_ : nullptr;
     lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g.p, lv.nstep.p, tm);
     if (live_) hip_check(hipEventRecord(e1, ctx_.stream), "record");
     launch_dot(ctx_.stream, N, lv.g.p, lv.nstep.p, partials_.p, scal_.p + 3);
     hip_check(hipMemcpyAsync(h_scal_.p + 3, scal_.p + 3, sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H inc");
     hip_check(hipMemcpyAsync(h_flag_.p, lv.gchol.fail_flag(), sizeof(int), hipMemcpyDeviceToHost, ctx_.stream), "D2H flag");
+    if (spec) {
+      enqueue_trial(lv, spec[0], 1.0, 0);
+      enqueue_trial(lv, spec[1], kBeta, 1);
+      st.n_f0 += 2;
+    }
     sync_collect("sync solve");
+    if (spec)
+      for (int q = 0; q < 2; ++q) {
+        spec[q].y = h_scal_.p[4 + 2 * q] + t * h_scal_.p[5 + 2 * q];
+        spec[q].valid = true;
+      }
     if (live_) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) st.time_factor += ms * 1e-3;
@@ -573,7 +599,6 @@ bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st,
   return ok;
 }
 
-static const double kBeta = 0.5, kArmijo = 0.1, kMinStep = 1e-8;
 // kFracToBoundary (amg.hpp) = oracle FRAC_TO_BOUNDARY; the loop below mirrors oracle newton() +
 // linesearch_backtracking() (REFINE = True) statement by statement.
 
@@ -620,44 +645,53 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
   st.n_f1++;
   double ymin = y, gmin = gnorm, incmin = INFINITY;
   const double theta = finest ? 0.1 : 0.5;
-  double* sA = lv.s_trial.p;
-  double* sB = lv.s_trial2.p;
-  double* phiA = phi_trial_.p;
-  double* phiB = phi_trial2_.p;
+  Trial T[2];
+  T[0].s = lv.s_trial.p;
+  T[0].phi = phi_trial_.p;
+  T[1].s = lv.s_trial2.p;
+  T[1].phi = phi_trial2_.p;
+  const double* dz_owner = lv.s.p;      // the point whose Dz currently sits in Dz_
+  // objective at s - step * nstep in T's buffers (served from the speculative evaluation when it matches)
+  auto eval = [&](Trial& X, double step) {
+    if (X.valid && X.step == step) return X.y;
+    launch_waxpby(ctx_.stream, N, lv.s.p, -step, lv.nstep.p, X.s);
+    X.y = dev_f0(lv, X.s, t, nullptr, phi_cur_.p, X.phi);
+    st.n_f0++;
+    X.step = step;
+    X.valid = true;
+    dz_owner = X.s;
+    return X.y;
+  };
   while (res.k < maxit && !res.converged) {
     res.k++;
     double inc = 0;
-    if (!dev_f2_solve(lv, lv.s.p, t, st, &inc)) break;
+    T[0].valid = T[1].valid = false;
+    const bool speculate = !host_solve_;
+    if (!dev_f2_solve(lv, lv.s.p, t, st, &inc, speculate ? T : nullptr)) break;
+    if (speculate) dz_owner = T[1].s;
     if (!std::isfinite(inc)) break;
     if (inc <= 0) {
       res.converged = true;
       break;
     }
     // backtracking line search: the trial must be finite (amgb_all_isfinite, src:121), respect the
-    // fraction-to-the-boundary rule and satisfy Armijo; then keep halving while the objective improves
+    // fraction-to-the-boundary rule and satisfy Armijo; then keep halving while the objective improves.
+    // T[0] plays the oracle's "current trial", T[1] its "next halving".
     double step = 1.0, ynext = y, gnext = gnorm;
     bool accepted = false;
     while (step >= kMinStep) {
-      launch_waxpby(ctx_.stream, N, lv.s.p, -step, lv.nstep.p, sA);
-      double yA = dev_f0(lv, sA, t, nullptr, phi_cur_.p, phiA);
-      st.n_f0++;
+      if (!(T[0].valid && T[0].step == step) && T[1].valid && T[1].step == step) std::swap(T[0], T[1]);
+      double yA = eval(T[0], step);
       if (std::isfinite(yA) && yA <= y - kArmijo * step * inc) {
-        bool dz_is_A = true;
         while (step * kBeta >= kMinStep) {
-          launch_waxpby(ctx_.stream, N, lv.s.p, -step * kBeta, lv.nstep.p, sB);
-          const double yB = dev_f0(lv, sB, t, nullptr, phi_cur_.p, phiB);
-          st.n_f0++;
-          if (!(std::isfinite(yB) && yB < yA)) {
-            dz_is_A = false;
-            break;
-          }
-          std::swap(sA, sB);
-          std::swap(phiA, phiB);
+          const double yB = eval(T[1], step * kBeta);
+          if (!(std::isfinite(yB) && yB < yA)) break;
+          std::swap(T[0], T[1]);
           yA = yB;
           step *= kBeta;
-          dz_is_A = true;
         }
-        const double gn = dev_f1(lv, sA, t, dz_is_A, lv.g_trial.p);
+        const double gn = dev_f1(lv, T[0].s, t, dz_owner == T[0].s, lv.g_trial.p);
+        dz_owner = T[0].s;
         st.n_f1++;
         if (std::isfinite(gn)) {
           ynext = yA;
@@ -669,10 +703,10 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
       step *= kBeta;
     }
     if (accepted) {
-      std::swap(lv.s.p, sA);
-      std::swap(phi_cur_.p, phiA);
+      std::swap(lv.s.p, T[0].s);
+      std::swap(phi_cur_.p, T[0].phi);
       std::swap(lv.g.p, lv.g_trial.p);
-      if (host_solve_) std::swap(lv.h_g.p, lv.h_g.p);   // h_g already holds the accepted gradient
+      dz_owner = lv.s.p;
     } else {
       step = 0.0;
       if (host_solve_)   // a rejected trial may have overwritten the host copy of the gradient
@@ -689,10 +723,10 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
       fprintf(stderr, "    [mgb] level %d k=%d y=%.12g |g|=%.3g inc=%.3g step=%.3g\n", l, res.k, y, gnorm, inc, step);
   }
   // hand the scratch buffers back (pointer identities may have rotated)
-  lv.s_trial.p = sA;
-  lv.s_trial2.p = sB;
-  phi_trial_.p = phiA;
-  phi_trial2_.p = phiB;
+  lv.s_trial.p = T[0].s;
+  lv.s_trial2.p = T[1].s;
+  phi_trial_.p = T[0].phi;
+  phi_trial2_.p = T[1].phi;
   return res;
 }
 

@@ -125,8 +125,8 @@ Csr build_dstack(const GeometryHost& g, const AmgSpec& spec);
 LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr& Dstack, int level,
                            const BarrierParams& P);
 
-// kernel classes timed live with HIP events (KernelTimer); the Cholesky classes are sampled on every 8th
-// factorisation to keep the event overhead below 1 %
+// kernel classes timed live with HIP events (KernelTimer) on every 8th Newton step (bracketing every launch
+// costs ~14 % of a solve)
 enum KernelClass {
   KC_APPLY = 0, KC_F2 = 1, KC_ASSEMBLE = 2, KC_F1 = 3, KC_RESTRICT = 4, KC_F0 = 5,
   KC_CHOL_START = 6, KC_CHOL_STEP = 7, KC_CHOL_BWD_RECT = 8, KC_CHOL_BWD = 9, KC_COUNT = 10
@@ -165,7 +165,9 @@ struct SolveStats {
 class KernelTimer {
  public:
   ~KernelTimer();
-  void enable(bool on) { on_ = on; }
+  void enable(bool on) { on_ = on; sampling_ = true; }
+  void sample(bool now) { sampling_ = now; }      // gate: only the Newton steps chosen for sampling are timed
+  bool sampling() const { return on_ && sampling_; }
   void begin(hipStream_t st, int cls, double bytes);
   void end(hipStream_t st);
   void collect(SolveStats& st);   // call only after the stream has been synchronised
@@ -177,7 +179,7 @@ class KernelTimer {
   };
   std::vector<Pair> free_, pending_;
   Pair cur_{};
-  bool on_ = false, open_ = false;
+  bool on_ = false, open_ = false, sampling_ = true;
 };
 
 class Amg {
@@ -245,7 +247,18 @@ class Amg {
   void dev_apply(Level& lv, const double* s_dev);                 // Dz = Dz0 + B s
   double dev_f0(Level& lv, const double* s_dev, double t, double* parts, const double* phi_ref, double* phi_out);
   double dev_f1(Level& lv, const double* s_dev, double t, bool reuse_dz, double* g_out);   // returns |g|
-  bool dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st, double* inc);  // -> lv.nstep
+  // one line-search trial point s - step * nstep with its scratch buffers and (cached) objective value
+  struct Trial {
+    double* s = nullptr;
+    double* phi = nullptr;
+    double step = 0, y = 0;
+    bool valid = false;
+  };
+  // Hessian at s, nstep = H \ g.  With `spec` (device solver only) the first two line-search trials (steps 1 and
+  // 1/2, the two points every line search evaluates first) are enqueued behind the solve and read back with the
+  // same host synchronisation: two fewer round trips per Newton step.
+  bool dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st, double* inc, Trial* spec = nullptr);
+  void enqueue_trial(Level& lv, Trial& T, double step, int slot);
   NewtonResult newton(int l, double t, bool finest, double lam_tol, int maxit, SolveStats& st, int verbose);
   bool amgb_step(double t, double lam_tol, int max_newton, std::vector<long long>& its, SolveStats& st, int verbose);
   double c_dot_dz();
