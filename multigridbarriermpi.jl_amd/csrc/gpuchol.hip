@@ -127,6 +127,7 @@ __device__ void factor_diag_block(const double* D, int kw, double* Lo, double* l
     }
   }
   __syncthreads();
+  if (lp == nullptr) return;      // workgroup-uniform: the caller keeps the factor in Lo only
   for (int idx = tid; idx < PB * PB; idx += blockDim.x) {
     lp[idx] = Lo[(idx / PB) * LP + idx % PB];               // row-major: lp[32 m + c] = L[m][c]
     lp[PB * PB + idx] = Lo[(idx % PB) * LP + idx / PB];     // column-major copy: L[m][j] at 32 j + m
@@ -397,6 +398,158 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   STAMP(7);
 }
 
+// Heights whose fronts all have a single panel (ns <= 32; at fem2d L=7 five of the eleven heights): front_start and
+// the one front_step collapse into ONE launch without any dependency between its workgroups.  Workgroup = 64x64
+// tile of the trailing matrix, as in front_step, but it GATHERS what it needs instead of reading an assembled front:
+// the pivot block (every tile re-derives and factors it -- 5 us of redundant work instead of a launch), its two
+// 64x32 panel blocks, and its C tile, each as child0 + child1 contribution through the inverse index maps, plus
+// the assembled matrix entries and the right-hand side (which only live in pivot columns).  Tile (0,0) publishes
+// the pivot block; the tj == 0 tiles the mirrored rows of L.
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void front_single_kernel(
+    const GNode* __restrict__ nodes, const StepTile* __restrict__ tiles, const int* __restrict__ pinv,
+    const int* __restrict__ asm_src, const int* __restrict__ asm_pos, const double* __restrict__ vals,
+    const int* __restrict__ perm, const double* __restrict__ b, const double* __restrict__ fronts_ro, double* fronts,
+    double* linv, int* fail, long long* prof) {
+  __shared__ __attribute__((aligned(32))) double sh[2 * PB * TS + PB * PB + 2 * PB * LP];
+  __shared__ int rowI[2][TS], rowJ[2][TS], piv[2][PB];
+  double* ATI = sh;
+  double* ATJ = sh + PB * TS;
+  double* Lc = sh + 2 * PB * TS;
+  double* D = Lc + PB * PB;
+  double* Lo = D + PB * LP;
+  STAMP(0);
+  const StepTile t = tiles[blockIdx.x];
+  const GNode nd = nodes[t.pad];
+  const int nf = nd.nf, ld = nf + 1, ns = nd.ns, kw = ns, k1 = ns;      // ns <= 32: one panel, k0 = 0
+  double* F = fronts + nd.off;
+  const int r0 = k1 + TS * t.ti, c0 = k1 + TS * t.tj;
+  const bool diag = (t.ti == t.tj);
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  long long boff[2] = {nd.off, nd.off};
+  int cld[2] = {0, 0};
+  bool has[2] = {false, false};
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    if (nd.child[s] >= 0) {
+      const GNode c = nodes[nd.child[s]];
+      cld[s] = c.nf + 1;
+      boff[s] = c.off + (long long)cld[s] * c.ns + c.ns;
+      has[s] = true;
+    }
+  const int* __restrict__ inv0 = pinv + (has[0] ? nd.iofs : 0);
+  const int* __restrict__ inv1 = pinv + (has[1] ? nd.iofs + ld : 0);
+  const double* __restrict__ B0 = fronts_ro + boff[0];
+  const double* __restrict__ B1 = fronts_ro + boff[1];
+  // index maps of the tile's rows, columns and of the pivot columns (parent front index -> child boundary index)
+  for (int idx = tid; idx < 2 * (2 * TS + PB); idx += TB) {
+    const int s = idx / (2 * TS + PB), q = idx % (2 * TS + PB);
+    const int* __restrict__ iv = s ? inv1 : inv0;
+    if (q < TS) rowI[s][q] = (has[s] && r0 + q <= nf) ? iv[r0 + q] : -1;
+    else if (q < 2 * TS) rowJ[s][q - TS] = (has[s] && c0 + q - TS <= nf) ? iv[c0 + q - TS] : -1;
+    else piv[s][q - 2 * TS] = (has[s] && q - 2 * TS < ns) ? iv[q - 2 * TS] : -1;
+  }
+  __syncthreads();
+  // gather (every load issued before it is consumed, clamped to a valid address when the entry has no contribution)
+  auto child = [&](int a0, int q0, int a1, int q1) {
+    const bool ok0 = a0 >= 0 && q0 >= 0, ok1 = a1 >= 0 && q1 >= 0;
+    const double x0 = B0[ok0 ? (long long)cld[0] * q0 + a0 : 0];
+    const double x1 = B1[ok1 ? (long long)cld[1] * q1 + a1 : 0];
+    return (ok0 ? x0 : 0.0) + (ok1 ? x1 : 0.0);
+  };
+  double c[4][4];
+#pragma unroll
+  for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+    for (int aq = 0; aq < 4; ++aq) {
+      const int r = tx + 16 * aq, cc = ty + 16 * bq, i = r0 + r, j = c0 + cc;
+      const bool in = (i <= nf && j < nf && i >= j);
+      c[aq][bq] = in ? child(rowI[0][r], rowJ[0][cc], rowI[1][r], rowJ[1][cc]) : 0.0;
+    }
+  {
+    const int r = tid % TS, qg = tid / TS;      // 64 rows x 4 groups of 8 pivot columns
+    double vi[8], vj[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = qg * 8 + u;
+      vi[u] = child(rowI[0][r], piv[0][q], rowI[1][r], piv[1][q]);
+      vj[u] = diag ? 0.0 : child(rowJ[0][r], piv[0][q], rowJ[1][r], piv[1][q]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      ATI[(qg * 8 + u) * TS + tile_pos(r)] = vi[u];
+      if (!diag) ATJ[(qg * 8 + u) * TS + tile_pos(r)] = vj[u];
+    }
+    const int i = tid % PB, jg = tid / PB;      // pivot block: 32 rows x 8 groups of 4 columns
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = jg * 4 + u;
+      D[i * LP + j] = (j <= i) ? child(piv[0][i], piv[0][j], piv[1][i], piv[1][j]) : 0.0;
+    }
+  }
+  __syncthreads();
+  STAMP(1);
+  // assembled entries (all in pivot columns) and right-hand side of the pieces this tile holds
+  for (int k = nd.a0 + tid; k < nd.a1; k += TB) {
+    const int pos = asm_pos[k], col = pos / ld, row = pos - col * ld;
+    const double v = vals[asm_src[k]];
+    if (row < ns) D[row * LP + col] += v;
+    else {
+      if (row >= r0 && row < r0 + TS) ATI[col * TS + tile_pos(row - r0)] += v;
+      if (!diag && row >= c0 && row < c0 + TS) ATJ[col * TS + tile_pos(row - c0)] += v;
+    }
+  }
+  if (nf >= r0 && nf < r0 + TS)
+    for (int q = tid; q < ns; q += TB) ATI[q * TS + tile_pos(nf - r0)] += b[perm[nd.first + q]];
+  __syncthreads();
+  factor_diag_block(D, kw, Lo, (t.ti == 0 && t.tj == 0) ? linv + nd.loff : nullptr, fail, nullptr);
+  for (int idx = tid; idx < PB * PB; idx += TB) Lc[idx] = Lo[(idx % PB) * LP + idx / PB];     // Lc[32 j + m] = L[m][j]
+  __syncthreads();
+  STAMP(2);
+  if (tid < 2 * TS && (tid < TS || !diag)) {
+    const int r = tid & (TS - 1);
+    double* A = ((tid < TS) ? ATI : ATJ) + tile_pos(r);
+    double f[PB];
+#pragma unroll
+    for (int m = 0; m < PB; ++m) f[m] = A[m * TS];
+    trsm_row(f, Lc);
+#pragma unroll
+    for (int m = 0; m < PB; ++m) A[m * TS] = f[m];
+    if (t.tj == 0 && tid < TS && r0 + r <= nf) {
+      double* Lrow = F + (long long)ld * (r0 + r);
+#pragma unroll
+      for (int m = 0; m < PB; ++m)
+        if (m < kw) Lrow[m] = f[m];
+    }
+  }
+  __syncthreads();
+  STAMP(3);
+  const double* LI = ATI + 4 * tx;
+  const double* LJ = (diag ? ATI : ATJ) + 4 * ty;
+  double acc[4][4];
+#pragma unroll
+  for (int aq = 0; aq < 4; ++aq)
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = 0.0;
+#pragma unroll 8
+  for (int q = 0; q < PB; ++q) {
+    const double4 xv = *reinterpret_cast<const double4*>(LI + q * TS);
+    const double4 yv = *reinterpret_cast<const double4*>(LJ + q * TS);
+    const double x[4] = {xv.x, xv.y, xv.z, xv.w}, y[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+    for (int aq = 0; aq < 4; ++aq)
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = fma(x[aq], y[bq], acc[aq][bq]);
+  }
+#pragma unroll
+  for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+    for (int aq = 0; aq < 4; ++aq) {
+      const int i = r0 + tx + 16 * aq, j = c0 + ty + 16 * bq;
+      if (i <= nf && j < nf && i >= j) F[(long long)ld * j + i] = c[aq][bq] - acc[aq][bq];
+    }
+  STAMP(7);
+}
+
 // s_j = sum_i L[ns+i][j] x_bdry[i] for the own columns j of one front: thread = (column, slice of the boundary
 // rows); L[i][j] sits at row j of column i, so the loads of a wave are unit-stride and independent.
 template <int NT>
@@ -618,8 +771,14 @@ void GpuChol::build(const MfChol& sym) {
       }
     }
     if (q != m) throw std::runtime_error("gpuchol: assembly entry outside the front");
+    nodes[t].a0 = sjobs[t].empty() ? 0 : sjobs[t].front().a0;
+    nodes[t].a1 = sjobs[t].empty() ? 0 : sjobs[t].back().a1;
   }
   // schedule
+  static const bool single_ok = [] {
+    const char* e = std::getenv("MGB_CHOL_SINGLE");
+    return !(e && e[0] == '0');
+  }();
   static const int split_nf = [] {
     const char* e = std::getenv("MGB_BWD_SPLIT_NF");
     return e ? std::atoi(e) : 192;
@@ -644,6 +803,13 @@ void GpuChol::build(const MfChol& sym) {
       }
     lists.insert(lists.end(), mine.begin(), mine.end());
     hp.nodes.cnt = (int)mine.size();
+    // single-panel heights with children: one dependency-free launch (front_single_kernel)
+    bool any_child = false, all_pivots = true;
+    for (int t : mine) {
+      any_child = any_child || nodes[t].child[0] >= 0 || nodes[t].child[1] >= 0;
+      all_pivots = all_pivots && nodes[t].ns >= 1;      // a pass-through front (ns = 0) needs front_start to copy it
+    }
+    hp.single = single_ok && max_ns <= PB && any_child && all_pivots;
     // front_start jobs
     hp.start.ofs = (int)starts.size();
     hp.start_bytes = 0;
@@ -656,7 +822,7 @@ void GpuChol::build(const MfChol& sym) {
         const double cnb = nodes[c].nf - nodes[c].ns;
         hp.start_bytes += 0.5 * cnb * cnb * 8.0;     // child entry read (the parent entry write is counted above)
       }
-      starts.insert(starts.end(), sjobs[t].begin(), sjobs[t].end());
+      if (!hp.single) starts.insert(starts.end(), sjobs[t].begin(), sjobs[t].end());
     }
     hp.start.cnt = (int)starts.size() - hp.start.ofs;
     launches_++;
@@ -676,6 +842,7 @@ void GpuChol::build(const MfChol& sym) {
           st.loff = g.loff + (long long)p * 2 * PB * PB;
           st.nf = g.nf;
           st.ns = g.ns;
+          st.pad = t;      // node index (front_single_kernel)
           if (pass == 0) {      // pivot workgroups first: they are the critical path of the next launch
             if (k1 < g.ns) {
               tiles.push_back(st);
@@ -793,6 +960,14 @@ void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, d
   int nprof = 0;
   for (int h = 0; h < nheights_; ++h) {
     const HeightPlan& hp = plan_[h];
+    if (hp.single) {
+      if (tm) tm->begin(st, KC_CHOL_STEP, hp.start_bytes + hp.step_bytes[0]);
+      hipLaunchKernelGGL(front_single_kernel, dim3(hp.step[0].cnt), dim3(TB), 0, st, d_nodes_, d_tiles_ + hp.step[0].ofs, d_pinv_,
+                         d_asm_src_, d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_fronts_, d_linv_, d_fail_,
+                         d_prof_ ? d_prof_ + 8 * (nprof++) : nullptr);
+      if (tm) tm->end(st);
+      continue;
+    }
     if (tm) tm->begin(st, KC_CHOL_START, hp.start_bytes);
     hipLaunchKernelGGL(front_start_kernel, dim3(hp.start.cnt), dim3(TB), 0, st, d_nodes_, d_start_ + hp.start.ofs, d_pinv_,
                        d_asm_src_, d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_fronts_, d_linv_, d_fail_,

@@ -39,6 +39,7 @@ struct GNode {
   int bofs;           // offset of this node's bdry / ea lists (nb entries each)
   int child[2];       // -1 if absent
   int iofs;           // offset of the two (nf+1)-long inverse extend-add maps (-1: leaf)
+  int a0, a1;         // range of this node's entries in the assembly list
 };
 
 struct StartJob {     // one workgroup of front_start: 32 columns x 256 rows (counted from the chunk's first row) of one front
@@ -51,7 +52,7 @@ struct StepTile {     // one workgroup of front_step: a 64x64 tile of the traili
   long long loff;     // offset of THIS panel's pivot block
   int nf, ns;
   short ti, tj;
-  int pad;
+  int pad;            // node index
 };
 
 struct RectJob {      // one workgroup of backward_rect: 64 own columns of one front
@@ -117,6 +118,7 @@ class GpuChol {
     double start_bytes, rect_bytes, tri_bytes;
     int max_nf;
     bool split;      // backward: rectangular part in its own multi-workgroup launch
+    bool single;     // every front has one panel: front_single replaces front_start + front_step
   };
   std::vector<HeightPlan> plan_;
   std::vector<void*> allocs_;
