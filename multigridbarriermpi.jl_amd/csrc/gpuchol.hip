@@ -406,7 +406,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 // the assembled matrix entries and the right-hand side (which only live in pivot columns).  Tile (0,0) publishes
 // the pivot block; the tj == 0 tiles the mirrored rows of L.
 __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void front_single_kernel(
-    const GNode* __restrict__ nodes, const StepTile* __restrict__ tiles, const int* __restrict__ pinv,
+    const SingleTile* __restrict__ tiles, const int* __restrict__ pinv,
     const int* __restrict__ asm_src, const int* __restrict__ asm_pos, const double* __restrict__ vals,
     const int* __restrict__ perm, const double* __restrict__ b, const double* __restrict__ fronts_ro, double* fronts,
     double* linv, int* fail, long long* prof) {
@@ -418,28 +418,18 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   double* D = Lc + PB * PB;
   double* Lo = D + PB * LP;
   STAMP(0);
-  const StepTile t = tiles[blockIdx.x];
-  const GNode nd = nodes[t.pad];
-  const int nf = nd.nf, ld = nf + 1, ns = nd.ns, kw = ns, k1 = ns;      // ns <= 32: one panel, k0 = 0
-  double* F = fronts + nd.off;
+  const SingleTile t = tiles[blockIdx.x];      // carries everything of the node and its children: no dependent loads
+  const int nf = t.nf, ld = nf + 1, ns = t.ns, kw = ns, k1 = ns;      // ns <= 32: one panel, k0 = 0
+  double* F = fronts + t.off;
   const int r0 = k1 + TS * t.ti, c0 = k1 + TS * t.tj;
   const bool diag = (t.ti == t.tj);
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  long long boff[2] = {nd.off, nd.off};
-  int cld[2] = {0, 0};
-  bool has[2] = {false, false};
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-    if (nd.child[s] >= 0) {
-      const GNode c = nodes[nd.child[s]];
-      cld[s] = c.nf + 1;
-      boff[s] = c.off + (long long)cld[s] * c.ns + c.ns;
-      has[s] = true;
-    }
-  const int* __restrict__ inv0 = pinv + (has[0] ? nd.iofs : 0);
-  const int* __restrict__ inv1 = pinv + (has[1] ? nd.iofs + ld : 0);
-  const double* __restrict__ B0 = fronts_ro + boff[0];
-  const double* __restrict__ B1 = fronts_ro + boff[1];
+  const bool has[2] = {t.cld[0] > 0, t.cld[1] > 0};
+  const int cld[2] = {t.cld[0], t.cld[1]};
+  const int* __restrict__ inv0 = pinv + (has[0] ? t.iofs : 0);
+  const int* __restrict__ inv1 = pinv + (has[1] ? t.iofs + ld : 0);
+  const double* __restrict__ B0 = fronts_ro + t.boff[0];
+  const double* __restrict__ B1 = fronts_ro + t.boff[1];
   // index maps of the tile's rows, columns and of the pivot columns (parent front index -> child boundary index)
   for (int idx = tid; idx < 2 * (2 * TS + PB); idx += TB) {
     const int s = idx / (2 * TS + PB), q = idx % (2 * TS + PB);
@@ -489,19 +479,32 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   __syncthreads();
   STAMP(1);
   // assembled entries (all in pivot columns) and right-hand side of the pieces this tile holds
-  for (int k = nd.a0 + tid; k < nd.a1; k += TB) {
-    const int pos = asm_pos[k], col = pos / ld, row = pos - col * ld;
-    const double v = vals[asm_src[k]];
-    if (row < ns) D[row * LP + col] += v;
-    else {
-      if (row >= r0 && row < r0 + TS) ATI[col * TS + tile_pos(row - r0)] += v;
-      if (!diag && row >= c0 && row < c0 + TS) ATJ[col * TS + tile_pos(row - c0)] += v;
+  for (int k0a = t.a0; k0a < t.a1; k0a += 4 * TB) {      // 4 entries per thread and pass: loads batched
+    int pos[4], src[4];
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0a + u * TB + tid;
+      pos[u] = (k < t.a1) ? asm_pos[k] : -1;
+      src[u] = (k < t.a1) ? asm_src[k] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = vals[src[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (pos[u] < 0) continue;
+      const int col = pos[u] / ld, row = pos[u] - col * ld;
+      if (row < ns) D[row * LP + col] += v[u];
+      else {
+        if (row >= r0 && row < r0 + TS) ATI[col * TS + tile_pos(row - r0)] += v[u];
+        if (!diag && row >= c0 && row < c0 + TS) ATJ[col * TS + tile_pos(row - c0)] += v[u];
+      }
     }
   }
   if (nf >= r0 && nf < r0 + TS)
-    for (int q = tid; q < ns; q += TB) ATI[q * TS + tile_pos(nf - r0)] += b[perm[nd.first + q]];
+    for (int q = tid; q < ns; q += TB) ATI[q * TS + tile_pos(nf - r0)] += b[perm[t.first + q]];
   __syncthreads();
-  factor_diag_block(D, kw, Lo, (t.ti == 0 && t.tj == 0) ? linv + nd.loff : nullptr, fail, nullptr);
+  factor_diag_block(D, kw, Lo, (t.ti == 0 && t.tj == 0) ? linv + t.loff : nullptr, fail, nullptr);
   for (int idx = tid; idx < PB * PB; idx += TB) Lc[idx] = Lo[(idx % PB) * LP + idx / PB];     // Lc[32 j + m] = L[m][j]
   __syncthreads();
   STAMP(2);
@@ -783,6 +786,7 @@ void GpuChol::build(const MfChol& sym) {
     const char* e = std::getenv("MGB_BWD_SPLIT_NF");
     return e ? std::atoi(e) : 192;
   }();
+  std::vector<SingleTile> singles;
   std::vector<int> lists;
   std::vector<StartJob> starts;
   std::vector<StepTile> tiles;
@@ -862,6 +866,34 @@ void GpuChol::build(const MfChol& sym) {
             }
         }
       hp.step_npiv.push_back(npiv);
+      if (hp.single) {      // same tiles, self-contained descriptors
+        hp.single_tiles.ofs = (int)singles.size();
+        for (int q = rt.ofs; q < (int)tiles.size(); ++q) {
+          const GNode& g = nodes[tiles[q].pad];
+          SingleTile u{};
+          u.off = g.off;
+          u.loff = g.loff;
+          u.nf = g.nf;
+          u.ns = g.ns;
+          u.iofs = g.iofs;
+          u.a0 = g.a0;
+          u.a1 = g.a1;
+          u.first = g.first;
+          u.ti = tiles[q].ti;
+          u.tj = tiles[q].tj;
+          for (int sI = 0; sI < 2; ++sI) {
+            u.boff[sI] = g.off;
+            u.cld[sI] = 0;
+            if (g.child[sI] >= 0) {
+              const GNode& c = nodes[g.child[sI]];
+              u.cld[sI] = c.nf + 1;
+              u.boff[sI] = c.off + (long long)u.cld[sI] * c.ns + c.ns;
+            }
+          }
+          singles.push_back(u);
+        }
+        hp.single_tiles.cnt = (int)singles.size() - hp.single_tiles.ofs;
+      }
       rt.cnt = (int)tiles.size() - rt.ofs;
       hp.step.push_back(rt);
       hp.step_bytes.push_back(bytes);
@@ -892,6 +924,7 @@ void GpuChol::build(const MfChol& sym) {
   d_lists_ = upload(lists);
   d_start_ = upload(starts);
   d_tiles_ = upload(tiles);
+  d_singles_ = upload(singles);
   d_rectjobs_ = upload(rects);
   ck(hipMalloc((void**)&d_fronts_, std::max<long long>(total_front_, 1) * sizeof(double)), "hipMalloc fronts");
   allocs_.push_back(d_fronts_);
@@ -962,7 +995,7 @@ void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, d
     const HeightPlan& hp = plan_[h];
     if (hp.single) {
       if (tm) tm->begin(st, KC_CHOL_STEP, hp.start_bytes + hp.step_bytes[0]);
-      hipLaunchKernelGGL(front_single_kernel, dim3(hp.step[0].cnt), dim3(TB), 0, st, d_nodes_, d_tiles_ + hp.step[0].ofs, d_pinv_,
+      hipLaunchKernelGGL(front_single_kernel, dim3(hp.single_tiles.cnt), dim3(TB), 0, st, d_singles_ + hp.single_tiles.ofs, d_pinv_,
                          d_asm_src_, d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_fronts_, d_linv_, d_fail_,
                          d_prof_ ? d_prof_ + 8 * (nprof++) : nullptr);
       if (tm) tm->end(st);

@@ -55,6 +55,14 @@ struct StepTile {     // one workgroup of front_step: a 64x64 tile of the traili
   int pad;            // node index
 };
 
+struct SingleTile {   // one workgroup of front_single: a tile of a single-panel front, with everything it needs inline
+  long long off, loff;      // front, pivot block
+  long long boff[2];        // first boundary entry of each child's front (own front offset if absent)
+  int cld[2];               // child leading dimensions (0 = no child)
+  int nf, ns, iofs, a0, a1, first;
+  short ti, tj;
+};
+
 struct RectJob {      // one workgroup of backward_rect: 64 own columns of one front
   int node, chunk;
 };
@@ -105,6 +113,7 @@ class GpuChol {
   int* d_lists_ = nullptr;        // node lists per height
   StartJob* d_start_ = nullptr;
   StepTile* d_tiles_ = nullptr;
+  SingleTile* d_singles_ = nullptr;
   RectJob* d_rectjobs_ = nullptr;
   // host schedule
   struct Range {
@@ -113,6 +122,7 @@ class GpuChol {
   struct HeightPlan {
     Range nodes, start, rect;
     std::vector<Range> step;
+    Range single_tiles{0, 0};
     std::vector<int> step_npiv;   // leading pivot workgroups of every step launch
     std::vector<double> step_bytes;
     double start_bytes, rect_bytes, tri_bytes;
