@@ -144,12 +144,12 @@ int mgb_amg_solve(mgb_amg a, double tol, double t0, double kappa, int maxit, int
 /* SOL_main fields (docs/src/api.md:97-101) of the last mgb_amg_solve */
 int mgb_amg_sol_info(mgb_amg a, int* nt, double* t_elapsed, double* time_factor, long long* counts4);
 int mgb_amg_sol_get(mgb_amg a, long long* its /* L x nt col-major */, double* ts, double* c_dot_Dz);
-/* live HIP-event timing of the 10 kernel classes accumulated over the last mgb_amg_solve (event pairs
+/* live HIP-event timing of the 11 kernel classes accumulated over the last mgb_amg_solve (event pairs
  * recorded on the context stream around single launches, on every 8th Newton step -- bracketing every launch
  * costs ~14 % of a solve): total ms, total algorithmic bytes, launches timed;
  * order = apply_D, barrier_f2, hessian_assemble, barrier_f1, restrict, barrier_f0,
- *         chol_front_start, chol_front_step, chol_backward_rect, chol_backward */
-int mgb_amg_sol_kernels(mgb_amg a, double* ms10, double* bytes10, long long* launches10);
+ *         chol_front_start, chol_front_step, chol_backward_rect, chol_backward, chol_front_single */
+int mgb_amg_sol_kernels(mgb_amg a, double* ms11, double* bytes11, long long* launches11);
 /* per-kernel device timings (HIP events on the context stream), ms and algorithmic bytes per launch:
  * order = apply_D, barrier_f2, hessian_assemble, barrier_f1, restrict, barrier_f0 */
 int mgb_amg_time_kernels(mgb_amg a, int level, int reps, double* ms6, double* bytes6);

@@ -631,7 +631,7 @@ class AMG:
                     kernels=kernels)
 
     KERNEL_NAMES = ("apply_D", "barrier_f2", "hessian_assemble", "barrier_f1", "restrict", "barrier_f0",
-                    "chol_front_start", "chol_front_step", "chol_backward_rect", "chol_backward")
+                    "chol_front_start", "chol_front_step", "chol_backward_rect", "chol_backward", "chol_front_single")
 
     def time_kernels(self, l, reps=50):
         ms = np.empty(6)

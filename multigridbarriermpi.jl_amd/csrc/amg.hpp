@@ -129,7 +129,7 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
 // costs ~14 % of a solve)
 enum KernelClass {
   KC_APPLY = 0, KC_F2 = 1, KC_ASSEMBLE = 2, KC_F1 = 3, KC_RESTRICT = 4, KC_F0 = 5,
-  KC_CHOL_START = 6, KC_CHOL_STEP = 7, KC_CHOL_BWD_RECT = 8, KC_CHOL_BWD = 9, KC_COUNT = 10
+  KC_CHOL_START = 6, KC_CHOL_STEP = 7, KC_CHOL_BWD_RECT = 8, KC_CHOL_BWD = 9, KC_CHOL_SINGLE = 10, KC_COUNT = 11
 };
 
 constexpr double kFracToBoundary = 0.1;   // == oracle FRAC_TO_BOUNDARY

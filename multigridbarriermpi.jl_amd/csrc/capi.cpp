@@ -658,13 +658,13 @@ int mgb_amg_sol_get(mgb_amg a, long long* its, double* ts, double* c_dot_Dz) {
     if (c_dot_Dz) std::copy(a->stats.c_dot_Dz.begin(), a->stats.c_dot_Dz.end(), c_dot_Dz);
   });
 }
-int mgb_amg_sol_kernels(mgb_amg a, double* ms10, double* bytes10, long long* launches10) {
+int mgb_amg_sol_kernels(mgb_amg a, double* ms11, double* bytes11, long long* launches11) {
   return guard([&] {
     need(a, "null amg");
     for (int i = 0; i < KC_COUNT; ++i) {
-      if (ms10) ms10[i] = a->stats.kern_ms[i];
-      if (bytes10) bytes10[i] = a->stats.kern_bytes[i];
-      if (launches10) launches10[i] = a->stats.kern_launches[i];
+      if (ms11) ms11[i] = a->stats.kern_ms[i];
+      if (bytes11) bytes11[i] = a->stats.kern_bytes[i];
+      if (launches11) launches11[i] = a->stats.kern_launches[i];
     }
   });
 }

@@ -994,7 +994,7 @@ void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, d
   for (int h = 0; h < nheights_; ++h) {
     const HeightPlan& hp = plan_[h];
     if (hp.single) {
-      if (tm) tm->begin(st, KC_CHOL_STEP, hp.start_bytes + hp.step_bytes[0]);
+      if (tm) tm->begin(st, KC_CHOL_SINGLE, hp.start_bytes + hp.step_bytes[0]);
       hipLaunchKernelGGL(front_single_kernel, dim3(hp.single_tiles.cnt), dim3(TB), 0, st, d_singles_ + hp.single_tiles.ofs, d_pinv_,
                          d_asm_src_, d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_fronts_, d_linv_, d_fail_,
                          d_prof_ ? d_prof_ + 8 * (nprof++) : nullptr);
