@@ -553,6 +553,104 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   STAMP(7);
 }
 
+// Leaf heights (no children) whose fronts fit LDS and whose trailing matrix after the first panel is one 64x64
+// tile (nf <= 95, ns <= 64; at fem2d L=7 the 1 024 leaves, nf ~ 64, ns ~ 35): ONE workgroup assembles the front in
+// LDS, runs its (at most two) panels -- pivot-block factor, panel rows by in-register substitution, rank-32
+// update on the 4x4 micro-tiles of the tile kernels -- and writes the Schur complement, the rows of L and the
+// pivot blocks back.  One launch replaces front_start + two front_step launches of the widest height of the tree.
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void front_leaf_kernel(
+    const GNode* __restrict__ nodes, const int* __restrict__ list, const int* __restrict__ asm_src,
+    const int* __restrict__ asm_pos, const double* __restrict__ vals, const int* __restrict__ perm,
+    const double* __restrict__ b, double* fronts, double* linv, int* fail, long long* prof) {
+  extern __shared__ __attribute__((aligned(32))) double sm[];
+  STAMP(0);
+  const GNode nd = nodes[list[blockIdx.x]];
+  const int nf = nd.nf, ld = nf + 1, ns = nd.ns, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  __shared__ __attribute__((aligned(32))) double fixed[PB * TS + 2 * PB * LP + PB * PB];
+  double* Fs = sm;                               // the front, (nf+1)-leading-dimension layout as in HBM
+  double* AT = fixed;                            // staging tile of the panel rows (front_step layout)
+  double* Lc = AT + PB * TS;
+  double* D = Lc + PB * PB;
+  double* Lo = D + PB * LP;
+  double* F = fronts + nd.off;
+  for (int idx = tid; idx < ld * nf; idx += TB) Fs[idx] = 0.0;
+  __syncthreads();
+  for (int k = nd.a0 + tid; k < nd.a1; k += TB) Fs[asm_pos[k]] += vals[asm_src[k]];
+  for (int c = tid; c < ns; c += TB) Fs[ld * c + nf] += b[perm[nd.first + c]];
+  __syncthreads();
+  STAMP(1);
+  auto panel = [&](const int p) {      // straight-line code for the (at most two) panels: a loop here made the
+                                        // compiler spill the substitution's registers
+    const int k0 = p * PB, kw = min(PB, ns - k0), k1 = k0 + kw;
+    for (int idx = tid; idx < PB * PB; idx += TB) {
+      const int i = idx % PB, j = idx / PB;
+      D[i * LP + j] = (i < kw && j <= i) ? Fs[ld * (k0 + j) + k0 + i] : 0.0;
+    }
+    __syncthreads();
+    factor_diag_block(D, kw, Lo, linv + nd.loff + (long long)p * 2 * PB * PB, fail, nullptr);
+    for (int idx = tid; idx < PB * PB; idx += TB) Lc[idx] = Lo[(idx % PB) * LP + idx / PB];     // Lc[32 j + m] = L[m][j]
+    __syncthreads();
+    // the (at most 64) panel rows k1..nf go through the transposed staging tile of the tile kernels, so that the
+    // substitution and the rank-32 update are literally the code of front_step (constant LDS strides)
+    for (int idx = tid; idx < TS * PB; idx += TB) {
+      const int r = idx % TS, q = idx / TS;
+      AT[q * TS + tile_pos(r)] = (q < kw && k1 + r <= nf) ? Fs[ld * (k0 + q) + k1 + r] : 0.0;
+    }
+    __syncthreads();
+    if (tid < TS) {
+      double* A = AT + tile_pos(tid);
+      double f[PB];
+#pragma unroll
+      for (int m = 0; m < PB; ++m) f[m] = A[m * TS];
+      trsm_row(f, Lc);
+#pragma unroll
+      for (int m = 0; m < PB; ++m) A[m * TS] = f[m];
+      if (k1 + tid <= nf) {
+        double* Lrow = F + (long long)ld * (k1 + tid) + k0;   // mirrored L for the backward sweep
+#pragma unroll
+        for (int m = 0; m < PB; ++m)
+          if (m < kw) Lrow[m] = f[m];
+      }
+    }
+    __syncthreads();
+    const double* LI = AT + 4 * tx;
+    const double* LJ = AT + 4 * ty;
+    double acc[4][4];
+#pragma unroll
+    for (int aq = 0; aq < 4; ++aq)
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = 0.0;
+#pragma unroll 8
+    for (int q = 0; q < PB; ++q) {
+      const double4 xv = *reinterpret_cast<const double4*>(LI + q * TS);
+      const double4 yv = *reinterpret_cast<const double4*>(LJ + q * TS);
+      const double x[4] = {xv.x, xv.y, xv.z, xv.w}, y[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+      for (int aq = 0; aq < 4; ++aq)
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = fma(x[aq], y[bq], acc[aq][bq]);
+    }
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+      for (int aq = 0; aq < 4; ++aq) {
+        const int i = k1 + tx + 16 * aq, j = k1 + ty + 16 * bq;
+        if (i <= nf && j < nf && i >= j) Fs[ld * j + i] -= acc[aq][bq];
+      }
+    __syncthreads();
+  };
+  panel(0);
+  if (ns > PB) panel(1);
+  STAMP(2);
+  // Schur complement + reduced right-hand side for the parent: boundary columns, rows down to nf
+  const int nb = nf - ns;
+  for (int idx = tid; idx < (nb + 1) * nb; idx += TB) {
+    const int i = ns + idx % (nb + 1), j = ns + idx / (nb + 1);
+    if (i >= j) F[(long long)ld * j + i] = Fs[ld * j + i];
+  }
+  STAMP(7);
+}
+
 // s_j = sum_i L[ns+i][j] x_bdry[i] for the own columns j of one front: thread = (column, slice of the boundary
 // rows); L[i][j] sits at row j of column i, so the loads of a wave are unit-stride and independent.
 template <int NT>
@@ -778,6 +876,10 @@ void GpuChol::build(const MfChol& sym) {
     nodes[t].a1 = sjobs[t].empty() ? 0 : sjobs[t].back().a1;
   }
   // schedule
+  static const bool leaf_ok = [] {
+    const char* e = std::getenv("MGB_CHOL_LEAF");
+    return !(e && e[0] == '0');
+  }();
   static const bool single_ok = [] {
     const char* e = std::getenv("MGB_CHOL_SINGLE");
     return !(e && e[0] == '0');
@@ -807,6 +909,12 @@ void GpuChol::build(const MfChol& sym) {
       }
     lists.insert(lists.end(), mine.begin(), mine.end());
     hp.nodes.cnt = (int)mine.size();
+    // leaf heights with small fronts: the whole front in one workgroup (front_leaf_kernel)
+    {
+      bool leaf = leaf_ok && hp.max_nf <= 95 && max_ns <= 2 * PB;
+      for (int t : mine) leaf = leaf && nodes[t].child[0] < 0 && nodes[t].child[1] < 0 && nodes[t].ns >= 1;
+      hp.leaf = leaf && !mine.empty();
+    }
     // single-panel heights with children: one dependency-free launch (front_single_kernel)
     bool any_child = false, all_pivots = true;
     for (int t : mine) {
@@ -826,12 +934,12 @@ void GpuChol::build(const MfChol& sym) {
         const double cnb = nodes[c].nf - nodes[c].ns;
         hp.start_bytes += 0.5 * cnb * cnb * 8.0;     // child entry read (the parent entry write is counted above)
       }
-      if (!hp.single) starts.insert(starts.end(), sjobs[t].begin(), sjobs[t].end());
+      if (!hp.single && !hp.leaf) starts.insert(starts.end(), sjobs[t].begin(), sjobs[t].end());
     }
     hp.start.cnt = (int)starts.size() - hp.start.ofs;
     launches_++;
     // front_step tiles, pivot-owning (0,0) tiles first
-    const int npanel = (max_ns + PB - 1) / PB;
+    const int npanel = hp.leaf ? 0 : (max_ns + PB - 1) / PB;
     for (int p = 0; p < npanel; ++p) {
       Range rt{(int)tiles.size(), 0};
       double bytes = 0;
@@ -949,6 +1057,7 @@ void GpuChol::build(const MfChol& sym) {
     ck(hipFuncSetAttribute((const void*)backward_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
     ck(hipFuncSetAttribute((const void*)backward_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
     ck(hipFuncSetAttribute((const void*)backward_rect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
+    ck(hipFuncSetAttribute((const void*)front_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024), "attr");
     attr_done = true;
   }
 }
@@ -993,6 +1102,15 @@ void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, d
   int nprof = 0;
   for (int h = 0; h < nheights_; ++h) {
     const HeightPlan& hp = plan_[h];
+    if (hp.leaf) {
+      if (tm) tm->begin(st, KC_CHOL_SINGLE, hp.start_bytes);
+      const size_t lds = (size_t)(hp.max_nf + 1) * hp.max_nf * sizeof(double);
+      hipLaunchKernelGGL(front_leaf_kernel, dim3(hp.nodes.cnt), dim3(TB), lds, st, d_nodes_, d_lists_ + hp.nodes.ofs, d_asm_src_,
+                         d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_linv_, d_fail_,
+                         d_prof_ ? d_prof_ + 8 * (nprof++) : nullptr);
+      if (tm) tm->end(st);
+      continue;
+    }
     if (hp.single) {
       if (tm) tm->begin(st, KC_CHOL_SINGLE, hp.start_bytes + hp.step_bytes[0]);
       hipLaunchKernelGGL(front_single_kernel, dim3(hp.single_tiles.cnt), dim3(TB), 0, st, d_singles_ + hp.single_tiles.ofs, d_pinv_,
