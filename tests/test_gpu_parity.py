@@ -368,3 +368,29 @@ def test_golden_level_vectors(M):
             H, _ = A.f2(l, sg, 2.5)
             assert rel(H.diagonal()[pi], gold["f2diag_%d" % l]) < 1e-11
             assert abs(np.sqrt(H.multiply(H).sum()) - gold["f2fro_%d" % l]) <= 1e-11 * gold["f2fro_%d" % l]
+
+
+def test_prepare_moves_the_factorisation_build_out_of_the_solve(M):
+    """AMG.prepare() (mgb_amg_prepare) builds level + factorisation structures up front; the solve that follows
+    gives the same answer as a lazily built one."""
+    g = M.fem2d_mpi(3)
+    x = g.x.to_numpy()
+    c = np.vstack([M.DEFAULT_F[2](xi) for xi in x])
+    z0 = np.vstack([M.DEFAULT_G[2](xi) for xi in x]).reshape(-1, order="F")
+    out = []
+    for prep in (True, False):
+        A = M.AMG(g, p=1.5)
+        A.set_c(c)
+        A.set_z(z0)
+        if prep:
+            A.prepare()
+        A.solve()
+        out.append(A.get_z())
+    assert np.array_equal(out[0], out[1])
+
+
+def test_more_than_eight_rows_of_D_are_rejected(M):
+    g = M.fem1d_mpi(3)
+    D = (("u", "id"),) * 8 + (("s", "id"),)
+    with pytest.raises(M.MGBError):
+        M.AMG(g, D=D, idx=[7, 8])
