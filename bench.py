@@ -191,7 +191,7 @@ def main():
                         avg_launch_us=1e3 * kd["ms"] / max(kd["launches"], 1), launches_timed=kd["launches"],
                         algorithmic_bytes_per_launch=kd["bytes"] / max(kd["launches"], 1),
                         note="latency-bound at this size: every working set is L2/Infinity-Cache resident and the "
-                             "factorisation + solve is a dependent chain of 49 short launches (DESIGN.md sections 4b, 5)",
+                             "factorisation + solve is a dependent chain of 47 short launches (DESIGN.md sections 4b, 5)",
                         all_kernels={k: dict(gbs=v["bytes"] / max(v["ms"], 1e-12) / 1e6,
                                              avg_us=1e3 * v["ms"] / max(v["launches"], 1), launches_timed=v["launches"],
                                              est_total_s=est[k] / 1e3 / args.steps)
