@@ -317,6 +317,8 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
   Dz0_.alloc((size_t)n_ * K);
   Dz0_save_.alloc((size_t)n_ * K);
   Dz_.alloc((size_t)n_ * K);
+  DzA_.alloc((size_t)n_ * K);
+  DzB_.alloc((size_t)n_ * K);
   v_.alloc((size_t)n_ * K);
   Y_.alloc((size_t)n_ * nY);
   phi_cur_.alloc((size_t)n_ * P.ncones);
@@ -474,17 +476,18 @@ void Amg::sync_collect(const char* what) {
 
 void Amg::refresh_dz0() { launch_spmv(ctx_.stream, Dstack_.view, z_.p, nullptr, Dz0_.p); }
 
-void Amg::dev_apply(Level& lv, const double* s_dev) {
+void Amg::dev_apply(Level& lv, const double* s_dev, double* dz) {
   timer_.begin(ctx_.stream, KC_APPLY, csr_bytes(lv.B.view, true));
-  launch_spmv(ctx_.stream, lv.B.view, s_dev, Dz0_.p, Dz_.p);
+  launch_spmv(ctx_.stream, lv.B.view, s_dev, Dz0_.p, dz);
   timer_.end(ctx_.stream);
 }
 
-double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts, const double* phi_ref, double* phi_out) {
-  dev_apply(lv, s_dev);
+double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts, const double* phi_ref, double* phi_out,
+                   double* dz) {
+  dev_apply(lv, s_dev, dz);
   timer_.begin(ctx_.stream, KC_F0, (double)n_ * (2 * P_.K + 2 + (phi_ref ? 1 : 0)) * 8);
   // phi_ref == nullptr: start of a Newton solve (records phi of the iterate); otherwise a line-search trial
-  launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, phi_ref, kFracToBoundary, phi_out, partials_.p, scal_.p);
+  launch_barrier_f0(ctx_.stream, n_, P_, dz, w_.p, c_.p, phi_ref, kFracToBoundary, phi_out, partials_.p, scal_.p);
   timer_.end(ctx_.stream);
   ctx_.allreduce_sum(scal_.p, 2);      // sharded: +inf (a row left the cone on some rank) survives the sum
   hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
@@ -497,10 +500,9 @@ double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts, cons
 }
 
 // gradient at s into g_out (device); returns |g|_2 (non-finite if any entry is)
-double Amg::dev_f1(Level& lv, const double* s_dev, double t, bool reuse_dz, double* g_out) {
-  if (!reuse_dz) dev_apply(lv, s_dev);
+double Amg::dev_f1(Level& lv, const double* dz, double t, double* g_out) {
   timer_.begin(ctx_.stream, KC_F1, (double)n_ * (3 * P_.K + 1) * 8);
-  launch_barrier_f1(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, t, v_.p);
+  launch_barrier_f1(ctx_.stream, n_, P_, dz, w_.p, c_.p, t, v_.p);
   timer_.end(ctx_.stream);
   timer_.begin(ctx_.stream, KC_RESTRICT, csr_bytes(lv.BT.view, false));
   launch_spmv(ctx_.stream, lv.BT.view, v_.p, nullptr, g_out);
@@ -522,22 +524,21 @@ static const double kBeta = 0.5, kArmijo = 0.1, kMinStep = 1e-8;      // oracle 
 // enqueue (no host sync): T.s = s - step * nstep, f0 there -> host slot h_scal_[4 + 2 slot .. +1]
 void Amg::enqueue_trial(Level& lv, Trial& T, double step, int slot) {
   launch_waxpby(ctx_.stream, lv.plan.N, lv.s.p, -step, lv.nstep.p, T.s);
-  dev_apply(lv, T.s);
+  dev_apply(lv, T.s, T.dz);
   double* out = scal_.p + 4 + 2 * slot;
   timer_.begin(ctx_.stream, KC_F0, (double)n_ * (2 * P_.K + 3) * 8);
-  launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, phi_cur_.p, kFracToBoundary, T.phi, partials_.p, out);
+  launch_barrier_f0(ctx_.stream, n_, P_, T.dz, w_.p, c_.p, phi_cur_.p, kFracToBoundary, T.phi, partials_.p, out);
   timer_.end(ctx_.stream);
   ctx_.allreduce_sum(out, 2);
   hip_check(hipMemcpyAsync(h_scal_.p + 4 + 2 * slot, out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H trial");
   T.step = step;
 }
 
-bool Amg::dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st, double* inc, Trial* spec) {
+bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, double* inc, Trial* spec) {
   const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
   ensure_chol(lv);
-  dev_apply(lv, s_dev);
   timer_.begin(ctx_.stream, KC_F2, (double)n_ * (P_.K + 1 + P_.nY()) * 8);
-  launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p);
+  launch_barrier_f2(ctx_.stream, n_, P_, dz, w_.p, Y_.p);
   timer_.end(ctx_.stream);
   timer_.begin(ctx_.stream, KC_ASSEMBLE, csr_bytes(lv.T.view, false));
   launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
@@ -611,7 +612,7 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
     return res;
   }
   hip_check(hipMemsetAsync(lv.s.p, 0, (size_t)N * sizeof(double), ctx_.stream), "memset s");
-  double y = dev_f0(lv, lv.s.p, t, nullptr, nullptr, phi_cur_.p);
+  double y = dev_f0(lv, lv.s.p, t, nullptr, nullptr, phi_cur_.p, Dz_.p);      // Dz_ = D(z + R s) of the iterate
   st.n_f0++;
   if (!std::isfinite(y)) {
     // diagnose: which rows left the cone
@@ -641,7 +642,7 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
              l, t, bad, n_, minphi, worst, y);
     throw std::runtime_error(buf);
   }
-  double gnorm = dev_f1(lv, lv.s.p, t, true, lv.g.p);
+  double gnorm = dev_f1(lv, Dz_.p, t, lv.g.p);
   st.n_f1++;
   double ymin = y, gmin = gnorm, incmin = INFINITY;
   const double theta = finest ? 0.1 : 0.5;
@@ -650,16 +651,16 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
   T[0].phi = phi_trial_.p;
   T[1].s = lv.s_trial2.p;
   T[1].phi = phi_trial2_.p;
-  const double* dz_owner = lv.s.p;      // the point whose Dz currently sits in Dz_
+  T[0].dz = DzA_.p;      // every trial keeps its own Dz: the accepted one becomes the iterate's, nothing is re-evaluated
+  T[1].dz = DzB_.p;
   // objective at s - step * nstep in T's buffers (served from the speculative evaluation when it matches)
   auto eval = [&](Trial& X, double step) {
     if (X.valid && X.step == step) return X.y;
     launch_waxpby(ctx_.stream, N, lv.s.p, -step, lv.nstep.p, X.s);
-    X.y = dev_f0(lv, X.s, t, nullptr, phi_cur_.p, X.phi);
+    X.y = dev_f0(lv, X.s, t, nullptr, phi_cur_.p, X.phi, X.dz);
     st.n_f0++;
     X.step = step;
     X.valid = true;
-    dz_owner = X.s;
     return X.y;
   };
   while (res.k < maxit && !res.converged) {
@@ -667,8 +668,7 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
     double inc = 0;
     T[0].valid = T[1].valid = false;
     const bool speculate = !host_solve_;
-    if (!dev_f2_solve(lv, lv.s.p, t, st, &inc, speculate ? T : nullptr)) break;
-    if (speculate) dz_owner = T[1].s;
+    if (!dev_f2_solve(lv, Dz_.p, t, st, &inc, speculate ? T : nullptr)) break;
     if (!std::isfinite(inc)) break;
     if (inc <= 0) {
       res.converged = true;
@@ -690,8 +690,7 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
           yA = yB;
           step *= kBeta;
         }
-        const double gn = dev_f1(lv, T[0].s, t, dz_owner == T[0].s, lv.g_trial.p);
-        dz_owner = T[0].s;
+        const double gn = dev_f1(lv, T[0].dz, t, lv.g_trial.p);
         st.n_f1++;
         if (std::isfinite(gn)) {
           ynext = yA;
@@ -706,7 +705,7 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
       std::swap(lv.s.p, T[0].s);
       std::swap(phi_cur_.p, T[0].phi);
       std::swap(lv.g.p, lv.g_trial.p);
-      dz_owner = lv.s.p;
+      std::swap(Dz_.p, T[0].dz);
     } else {
       step = 0.0;
       if (host_solve_)   // a rejected trial may have overwritten the host copy of the gradient
@@ -727,6 +726,8 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
   lv.s_trial2.p = T[1].s;
   phi_trial_.p = T[0].phi;
   phi_trial2_.p = T[1].phi;
+  DzA_.p = T[0].dz;
+  DzB_.p = T[1].dz;
   return res;
 }
 
@@ -742,7 +743,6 @@ bool Amg::amgb_step(double t, double lam_tol, int max_newton, std::vector<long l
       launch_spmv(ctx_.stream, lv.R.view, lv.s.p, z_.p, z_.p);
       // carry the ACCEPTED Dz forward as the next Dz0 (bit-for-bit the values verified to be inside the
       // cone) instead of re-evaluating D(z + R s): see oracle Barrier._Dz
-      dev_apply(lv, lv.s.p);
       hip_check(hipMemcpyAsync(Dz0_.p, Dz_.p, (size_t)n_ * P_.K * sizeof(double), hipMemcpyDeviceToDevice,
                                ctx_.stream), "Dz0 <- Dz");
     }
@@ -835,21 +835,22 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
 double Amg::f0(int l, const double* s_host, double t, double* parts) {
   Level& lv = level(l);
   lv.s_trial.upload(s_host, lv.plan.N);
-  return dev_f0(lv, lv.s_trial.p, t, parts, nullptr, phi_cur_.p);
+  return dev_f0(lv, lv.s_trial.p, t, parts, nullptr, phi_cur_.p, Dz_.p);
 }
 
 double Amg::f0_trial(int l, const double* s_ref_host, const double* s_host, double t) {
   Level& lv = level(l);
   lv.s_trial.upload(s_ref_host, lv.plan.N);
-  dev_f0(lv, lv.s_trial.p, t, nullptr, nullptr, phi_cur_.p);     // records phi of the reference iterate
+  dev_f0(lv, lv.s_trial.p, t, nullptr, nullptr, phi_cur_.p, Dz_.p);     // records phi of the reference iterate
   lv.s_trial.upload(s_host, lv.plan.N);
-  return dev_f0(lv, lv.s_trial.p, t, nullptr, phi_cur_.p, phi_trial_.p);
+  return dev_f0(lv, lv.s_trial.p, t, nullptr, phi_cur_.p, phi_trial_.p, Dz_.p);
 }
 
 void Amg::f1(int l, const double* s_host, double t, double* g_host) {
   Level& lv = level(l);
   lv.s_trial.upload(s_host, lv.plan.N);
-  dev_f1(lv, lv.s_trial.p, t, false, lv.g_trial.p);
+  dev_apply(lv, lv.s_trial.p, Dz_.p);
+  dev_f1(lv, Dz_.p, t, lv.g_trial.p);
   lv.g_trial.download(g_host, lv.plan.N);
 }
 
@@ -857,7 +858,7 @@ void Amg::f2(int l, const double* s_host, double t, double* avals_host) {
   (void)t;
   Level& lv = level(l);
   lv.s_trial.upload(s_host, lv.plan.N);
-  dev_apply(lv, lv.s_trial.p);
+  dev_apply(lv, lv.s_trial.p, Dz_.p);
   launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p);
   launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
   ctx_.allreduce_sum(lv.avals.p, lv.plan.Apat.nnz());
@@ -868,7 +869,7 @@ void Amg::f2(int l, const double* s_host, double t, double* avals_host) {
 void Amg::apply_D(int l, const double* s_host, double* Dz_host) {
   Level& lv = level(l);
   lv.s_trial.upload(s_host, lv.plan.N);
-  dev_apply(lv, lv.s_trial.p);
+  dev_apply(lv, lv.s_trial.p, Dz_.p);
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   Dz_.download(Dz_host, (size_t)n_ * P_.K);
 }
@@ -913,7 +914,7 @@ Amg::KernelTimes Amg::time_kernels(int l, int reps) {
     return (double)ms / reps;
   };
   const double n = n_, K = P_.K, nY = P_.nY();
-  kt.apply_ms = timeit([&] { dev_apply(lv, lv.s.p); });
+  kt.apply_ms = timeit([&] { dev_apply(lv, lv.s.p, Dz_.p); });
   kt.apply_bytes = csr_bytes(lv.B.view, true);
   kt.f2_ms = timeit([&] { launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p); });
   kt.f2_bytes = n * (K + 1 + nY) * 8;

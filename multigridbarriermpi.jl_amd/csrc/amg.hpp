@@ -244,20 +244,22 @@ class Amg {
   Level& level(int l);            // lazily built
   void ensure_chol(Level& lv);    // factorisation structures, built on first solve
   void refresh_dz0();
-  void dev_apply(Level& lv, const double* s_dev);                 // Dz = Dz0 + B s
-  double dev_f0(Level& lv, const double* s_dev, double t, double* parts, const double* phi_ref, double* phi_out);
-  double dev_f1(Level& lv, const double* s_dev, double t, bool reuse_dz, double* g_out);   // returns |g|
+  void dev_apply(Level& lv, const double* s_dev, double* dz);     // dz = Dz0 + B s
+  double dev_f0(Level& lv, const double* s_dev, double t, double* parts, const double* phi_ref, double* phi_out,
+                double* dz);      // evaluates D at s into dz first
+  double dev_f1(Level& lv, const double* dz, double t, double* g_out);   // gradient from the Dz of the point; returns |g|
   // one line-search trial point s - step * nstep with its scratch buffers and (cached) objective value
   struct Trial {
     double* s = nullptr;
     double* phi = nullptr;
+    double* dz = nullptr;      // D at the trial point (n x K)
     double step = 0, y = 0;
     bool valid = false;
   };
   // Hessian at s, nstep = H \ g.  With `spec` (device solver only) the first two line-search trials (steps 1 and
   // 1/2, the two points every line search evaluates first) are enqueued behind the solve and read back with the
   // same host synchronisation: two fewer round trips per Newton step.
-  bool dev_f2_solve(Level& lv, const double* s_dev, double t, SolveStats& st, double* inc, Trial* spec = nullptr);
+  bool dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, double* inc, Trial* spec = nullptr);
   void enqueue_trial(Level& lv, Trial& T, double step, int slot);
   NewtonResult newton(int l, double t, bool finest, double lam_tol, int maxit, SolveStats& st, int verbose);
   bool amgb_step(double t, double lam_tol, int max_newton, std::vector<long long>& its, SolveStats& st, int verbose);
@@ -272,7 +274,7 @@ class Amg {
   Csr dstack_host_;
   DevCsrOwned Dstack_;
   std::vector<std::unique_ptr<Level>> levels_;
-  DevBuf<double> w_, c_, z_, z_save_, Dz0_, Dz0_save_, Dz_, v_, Y_, partials_, scal_, phi_cur_, phi_trial_, phi_trial2_;
+  DevBuf<double> w_, c_, z_, z_save_, Dz0_, Dz0_save_, Dz_, DzA_, DzB_, v_, Y_, partials_, scal_, phi_cur_, phi_trial_, phi_trial2_;
   PinnedBuf<int> h_flag_;
   bool host_solve_ = false;
   PinnedBuf<double> h_scal_;
