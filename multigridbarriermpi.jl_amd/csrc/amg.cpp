@@ -668,8 +668,14 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
     double inc = 0;
     T[0].valid = T[1].valid = false;
     const bool speculate = !host_solve_;
-    if (!dev_f2_solve(lv, Dz_.p, t, st, &inc, speculate ? T : nullptr)) break;
-    if (!std::isfinite(inc)) break;
+    if (!dev_f2_solve(lv, Dz_.p, t, st, &inc, speculate ? T : nullptr)) {
+      if (verbose > 1) fprintf(stderr, "    [mgb] level %d k=%d: Hessian not numerically SPD (pivot flag %d)\n", l, res.k, h_flag_.p[0]);
+      break;
+    }
+    if (!std::isfinite(inc)) {
+      if (verbose > 1) fprintf(stderr, "    [mgb] level %d k=%d: non-finite Newton decrement\n", l, res.k);
+      break;
+    }
     if (inc <= 0) {
       res.converged = true;
       break;

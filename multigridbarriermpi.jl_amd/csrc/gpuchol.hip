@@ -1071,6 +1071,9 @@ void GpuChol::factor_solve(hipStream_t st, const double* d_vals, const double* d
     const char* e = std::getenv("MGB_CHOL_GRAPH");
     return !(e && e[0] == '0');
   }();
+  // the pivot flag is re-armed here, outside the captured chain (a memset node replayed from the graph was seen
+  // to leave garbage in the flag when another library used the device between replays)
+  ck(hipMemsetAsync(d_fail_, 0, sizeof(int), st), "memset flag");
   if (!use_graph || tm || d_prof_) {
     enqueue(st, d_vals, d_b, d_x, tm);
     return;
@@ -1098,7 +1101,6 @@ void GpuChol::factor_solve(hipStream_t st, const double* d_vals, const double* d
 }
 
 void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm) {
-  ck(hipMemsetAsync(d_fail_, 0, sizeof(int), st), "memset flag");
   int nprof = 0;
   for (int h = 0; h < nheights_; ++h) {
     const HeightPlan& hp = plan_[h];

@@ -167,7 +167,7 @@ def _gpu_worker(rank, world, port, q, kind, L, p):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,L,p", [("fem1d", 4, 1.0), ("fem2d", 3, 1.5)])
+@pytest.mark.parametrize("kind,L,p", [("fem1d", 4, 1.0), ("fem2d", 3, 1.5), ("fem2d", 5, 1.5)])   # L=5: hipGraph replay path
 def test_sharded_solve_matches_unsharded_two_processes_one_gpu(gpu_required, kind, L, p):
     import mgb_amd as M
     ref = M.mpi_to_native(getattr(M, kind + "_mpi_solve")(L=L, p=p)).z
