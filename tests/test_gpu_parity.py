@@ -394,3 +394,14 @@ def test_more_than_eight_rows_of_D_are_rejected(M):
     D = (("u", "id"),) * 8 + (("s", "id"),)
     with pytest.raises(M.MGBError):
         M.AMG(g, D=D, idx=[7, 8])
+
+
+def test_quick_jl_custom_tolerance(M):
+    """test/test_quick.jl:108,137-140: fem1d L=3, `amgb(g; p=1, tol=1e-10)` (a non-default tolerance: the
+    t-continuation runs to 1/tol = 1e10), MPI-vs-native difference < 1e-7 there; here device vs oracle at 1e-10."""
+    sol = M.fem1d_mpi_solve(L=3, p=1.0, tol=1e-10)
+    ref = O.fem1d_solve(L=3, p=1.0, tol=1e-10)
+    z = M.mpi_to_native(sol).z
+    assert sol.SOL_main["ts"][-1] > 1e10 and ref.SOL_main["ts"][-1] > 1e10
+    assert np.linalg.norm(z - ref.z) < 1e-7
+    assert np.linalg.norm(z - ref.z) <= 1e-10 * np.linalg.norm(ref.z)
