@@ -405,3 +405,14 @@ def test_quick_jl_custom_tolerance(M):
     assert sol.SOL_main["ts"][-1] > 1e10 and ref.SOL_main["ts"][-1] > 1e10
     assert np.linalg.norm(z - ref.z) < 1e-7
     assert np.linalg.norm(z - ref.z) <= 1e-10 * np.linalg.norm(ref.z)
+
+
+@pytest.mark.parametrize("kind,L,p,kw", [("fem1d", 1, 1.0, {}), ("fem2d", 1, 3.0, {}), ("fem3d", 1, 2.0, {"k": 2}),
+                                         ("fem3d", 2, 1.5, {"k": 1})])
+def test_tiny_meshes_match_oracle(M, kind, L, p, kw):
+    """Smallest meshes (4 .. 64 rows): single-front elimination trees, empty boundaries, fronts below one panel."""
+    sol = getattr(M, kind + "_mpi_solve")(L=L, p=p, **kw)
+    ref = getattr(O, kind + "_solve")(L=L, p=p, **kw)
+    z = M.mpi_to_native(sol).z
+    assert z.shape == ref.z.shape
+    assert np.linalg.norm(z - ref.z) <= 1e-10 * np.linalg.norm(ref.z)
