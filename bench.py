@@ -215,13 +215,13 @@ def main():
         }
         if sharded:
             out["allreduce"] = backend.comm_stats()
-        if args.probe_L > 0 and not sharded:
+        if args.probe_L > 0 and world == 1:      # N=1 only, like the CPU baseline
             # secondary evidence for the bandwidth-shaped kernels: same kernels, back-to-back
             # launches, on the workload mesh (cache resident, launch bound) and on a mesh that exceeds L2
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import spmv_roofline
             out["kernel_bandwidth_probe"] = [spmv_roofline.probe(L, args.p) for L in sorted({args.L, args.probe_L})]
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the contract: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.L, args.p, args.cpu_budget)
         print(json.dumps(out))
     if dist is not None:
