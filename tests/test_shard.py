@@ -203,3 +203,13 @@ def test_rccl_allreduce_callback_on_a_raw_device_pointer(gpu_required):
     call and the stream hand-over that bench.py --shard relies on."""
     out = _run(_nccl_worker, 1)
     assert out[0][1] == 999 * 1000 / 2
+
+
+def test_plan_shards_sum_to_the_full_plan_gloo_world3_uneven():
+    """Three ranks: 8 / 32 elements do not divide evenly, the row blocks differ in size and still partition."""
+    out = _run(_shard_worker, 3)
+    for kind in out[0][1]:
+        blocks = [o[1][kind] for o in out]
+        assert blocks[0][0] == 0 and blocks[-1][1] == blocks[0][2]
+        assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+        assert len({b[1] - b[0] for b in blocks}) > 1          # uneven
