@@ -530,8 +530,7 @@ void Amg::enqueue_trial(Level& lv, Trial& T, double step, int slot) {
   launch_barrier_f0(ctx_.stream, n_, P_, T.dz, w_.p, c_.p, phi_cur_.p, kFracToBoundary, T.phi, partials_.p, out);
   timer_.end(ctx_.stream);
   ctx_.allreduce_sum(out, 2);
-  hip_check(hipMemcpyAsync(h_scal_.p + 4 + 2 * slot, out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H trial");
-  T.step = step;
+  T.step = step;      // the caller copies scal_[3..7] (inc + both trials) back in one transfer
 }
 
 bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, double* inc, Trial* spec) {
@@ -560,13 +559,14 @@ bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, do
     lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g.p, lv.nstep.p, tm);
     if (live_) hip_check(hipEventRecord(e1, ctx_.stream), "record");
     launch_dot(ctx_.stream, N, lv.g.p, lv.nstep.p, partials_.p, scal_.p + 3);
-    hip_check(hipMemcpyAsync(h_scal_.p + 3, scal_.p + 3, sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H inc");
     hip_check(hipMemcpyAsync(h_flag_.p, lv.gchol.fail_flag(), sizeof(int), hipMemcpyDeviceToHost, ctx_.stream), "D2H flag");
     if (spec) {
       enqueue_trial(lv, spec[0], 1.0, 0);
       enqueue_trial(lv, spec[1], kBeta, 1);
       st.n_f0 += 2;
     }
+    hip_check(hipMemcpyAsync(h_scal_.p + 3, scal_.p + 3, (spec ? 5 : 1) * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
+              "D2H inc + trials");
     sync_collect("sync solve");
     if (spec)
       for (int q = 0; q < 2; ++q) {
