@@ -251,6 +251,22 @@ __device__ inline void trsm_row(double (&f)[PB], const double* Lc) {
   }
 }
 
+// the same substitution straight from the ROW-major factor Lo (stride LP; broadcast reads do not care about the
+// stride) with a one-column register window: front_leaf_kernel trades the last LDS latency for occupancy
+__device__ inline void trsm_row_lo(double (&f)[PB], const double* Lo) {
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    double lc[PB];
+#pragma unroll
+    for (int m = j; m < PB; ++m) lc[m] = Lo[m * LP + j];
+    asm volatile("" ::: "memory");
+    const double fj = f[j] * lc[j];
+    f[j] = fj;
+#pragma unroll
+    for (int m = j + 1; m < PB; ++m) f[m] = fma(-fj, lc[m], f[m]);
+  }
+}
+
 // Critical path of a panel step, run by a dedicated workgroup per front: rows k1..k1+31 of the panel are solved
 // against the current pivot block, the 32x32 corner C[k1:k1+32, k1:k1+32] gets its rank-32 update, and the result
 // -- the next pivot block -- is factored and published.  The regular tile (0,0) of the same launch handles the
@@ -558,7 +574,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 // LDS, runs its (at most two) panels -- pivot-block factor, panel rows by in-register substitution, rank-32
 // update on the 4x4 micro-tiles of the tile kernels -- and writes the Schur complement, the rows of L and the
 // pivot blocks back.  One launch replaces front_start + two front_step launches of the widest height of the tree.
-__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void front_leaf_kernel(
+__global__ __launch_bounds__(TB, 3) void front_leaf_kernel(
     const GNode* __restrict__ nodes, const int* __restrict__ list, const int* __restrict__ asm_src,
     const int* __restrict__ asm_pos, const double* __restrict__ vals, const int* __restrict__ perm,
     const double* __restrict__ b, double* fronts, double* linv, int* fail, long long* prof) {
@@ -566,17 +582,23 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   STAMP(0);
   const GNode nd = nodes[list[blockIdx.x]];
   const int nf = nd.nf, ld = nf + 1, ns = nd.ns, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  __shared__ __attribute__((aligned(32))) double fixed[PB * TS + 2 * PB * LP + PB * PB];
+  __shared__ __attribute__((aligned(32))) double fixed[2 * PB * LP + PB * LP];      // AT (also D) | Lo
   double* Fs = sm;                               // the front, (nf+1)-leading-dimension layout as in HBM
-  double* AT = fixed;                            // staging tile of the panel rows (front_step layout)
-  double* Lc = AT + PB * TS;
-  double* D = Lc + PB * PB;
-  double* Lo = D + PB * LP;
+  double* AT = fixed;                            // staging tile of the panel rows (front_step layout), 32 x 64
+  double* D = fixed;                             // the pivot block is dead once factored: same storage
+  double* Lo = fixed + 2 * PB * LP;              // row-major factor, reciprocal diagonal
+  // packed lower-triangular storage of the front (column j holds rows j..nf): half the LDS of the square layout,
+  // which is what lets three workgroups share a CU
+  auto P = [ld](int i, int j) { return j * ld - (j * (j - 1)) / 2 + (i - j); };
+  const int total = nf * ld - (nf * (nf - 1)) / 2;
   double* F = fronts + nd.off;
-  for (int idx = tid; idx < ld * nf; idx += TB) Fs[idx] = 0.0;
+  for (int idx = tid; idx < total; idx += TB) Fs[idx] = 0.0;
   __syncthreads();
-  for (int k = nd.a0 + tid; k < nd.a1; k += TB) Fs[asm_pos[k]] += vals[asm_src[k]];
-  for (int c = tid; c < ns; c += TB) Fs[ld * c + nf] += b[perm[nd.first + c]];
+  for (int k = nd.a0 + tid; k < nd.a1; k += TB) {
+    const int pos = asm_pos[k], col = pos / ld;
+    Fs[P(pos - col * ld, col)] += vals[asm_src[k]];
+  }
+  for (int c = tid; c < ns; c += TB) Fs[P(nf, c)] += b[perm[nd.first + c]];
   __syncthreads();
   STAMP(1);
   auto panel = [&](const int p) {      // straight-line code for the (at most two) panels: a loop here made the
@@ -584,17 +606,15 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     const int k0 = p * PB, kw = min(PB, ns - k0), k1 = k0 + kw;
     for (int idx = tid; idx < PB * PB; idx += TB) {
       const int i = idx % PB, j = idx / PB;
-      D[i * LP + j] = (i < kw && j <= i) ? Fs[ld * (k0 + j) + k0 + i] : 0.0;
+      D[i * LP + j] = (i < kw && j <= i) ? Fs[P(k0 + i, k0 + j)] : 0.0;
     }
     __syncthreads();
     factor_diag_block(D, kw, Lo, linv + nd.loff + (long long)p * 2 * PB * PB, fail, nullptr);
-    for (int idx = tid; idx < PB * PB; idx += TB) Lc[idx] = Lo[(idx % PB) * LP + idx / PB];     // Lc[32 j + m] = L[m][j]
-    __syncthreads();
     // the (at most 64) panel rows k1..nf go through the transposed staging tile of the tile kernels, so that the
     // substitution and the rank-32 update are literally the code of front_step (constant LDS strides)
     for (int idx = tid; idx < TS * PB; idx += TB) {
       const int r = idx % TS, q = idx / TS;
-      AT[q * TS + tile_pos(r)] = (q < kw && k1 + r <= nf) ? Fs[ld * (k0 + q) + k1 + r] : 0.0;
+      AT[q * TS + tile_pos(r)] = (q < kw && k1 + r <= nf) ? Fs[P(k1 + r, k0 + q)] : 0.0;
     }
     __syncthreads();
     if (tid < TS) {
@@ -602,7 +622,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       double f[PB];
 #pragma unroll
       for (int m = 0; m < PB; ++m) f[m] = A[m * TS];
-      trsm_row(f, Lc);
+      trsm_row_lo(f, Lo);
 #pragma unroll
       for (int m = 0; m < PB; ++m) A[m * TS] = f[m];
       if (k1 + tid <= nf) {
@@ -635,7 +655,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #pragma unroll
       for (int aq = 0; aq < 4; ++aq) {
         const int i = k1 + tx + 16 * aq, j = k1 + ty + 16 * bq;
-        if (i <= nf && j < nf && i >= j) Fs[ld * j + i] -= acc[aq][bq];
+        if (i <= nf && j < nf && i >= j) Fs[P(i, j)] -= acc[aq][bq];
       }
     __syncthreads();
   };
@@ -646,7 +666,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   const int nb = nf - ns;
   for (int idx = tid; idx < (nb + 1) * nb; idx += TB) {
     const int i = ns + idx % (nb + 1), j = ns + idx / (nb + 1);
-    if (i >= j) F[(long long)ld * j + i] = Fs[ld * j + i];
+    if (i >= j) F[(long long)ld * j + i] = Fs[P(i, j)];
   }
   STAMP(7);
 }
@@ -1106,7 +1126,7 @@ void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, d
     const HeightPlan& hp = plan_[h];
     if (hp.leaf) {
       if (tm) tm->begin(st, KC_CHOL_SINGLE, hp.start_bytes);
-      const size_t lds = (size_t)(hp.max_nf + 1) * hp.max_nf * sizeof(double);
+      const size_t lds = ((size_t)(hp.max_nf + 1) * hp.max_nf - (size_t)hp.max_nf * (hp.max_nf - 1) / 2) * sizeof(double);
       hipLaunchKernelGGL(front_leaf_kernel, dim3(hp.nodes.cnt), dim3(TB), lds, st, d_nodes_, d_lists_ + hp.nodes.ofs, d_asm_src_,
                          d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_linv_, d_fail_,
                          d_prof_ ? d_prof_ + 8 * (nprof++) : nullptr);
