@@ -232,3 +232,32 @@ def test_hessian_plan_fem3d_k5_barrier():
         destroy()
         assert N == M.R[level].shape[1]
         assert np.abs(got - want).max() < 1e-12 * max(1.0, np.abs(want).max())
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/mgb_hip.h must be consumable from C (the reference-side binding is a C FFI): compile a C99 translation
+    unit that takes the address of every declared function, link it against libmgb_hip.so and run it."""
+    import re
+    import shutil
+    import subprocess
+    from mgb_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "mgb_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(mgb_[A-Za-z0-9_]+)\s*\(", hdr)) - {"mgb_allreduce_fn"})
+    assert set(names) == set(_lib.PROTOTYPES) | set(_lib._SPECIAL)
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include "mgb_hip.h"\n'
+                   "typedef void (*fn)(void);\nstatic fn table[] = {\n" +
+                   "".join("  (fn)%s,\n" % n for n in names) +
+                   "};\nint main(void) {\n  size_t i, n = sizeof table / sizeof table[0];\n"
+                   "  for (i = 0; i < n; ++i) if (!table[i]) return 1;\n"
+                   '  printf("%d %d\\n", mgb_version(), (int)n);\n  return mgb_device_count() < 0;\n}\n')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src),
+                    "-L", libdir, "-lmgb_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)],
+                   check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == 100 and int(out[1]) == len(names)
