@@ -214,6 +214,44 @@ class HPCMatrix:
         return HPCVector(self.to_numpy()[:, j], self.backend)
 
 
+def hpc_partition(m: int, world: int) -> np.ndarray:
+    """1-based offsets of the balanced contiguous split of m rows over `world` ranks (first m mod world ranks hold
+    one extra row) -- the shape of the reference's `row_partition` / `.partition` vectors (tools/profile_solve.jl:24).
+    HPCSparseArrays' own rule is not vendored in the reference [UPSTREAM-UNVERIFIED]."""
+    return np.array([1 + (m // world) * r + min(r, m % world) for r in range(world + 1)], dtype=np.int64)
+
+
+def hpc_local_block(S, rank: int, world: int, Ti=np.int32) -> dict:
+    """The fields rank `rank` of `world` holds for the sparse matrix S in the reference's distributed layout
+    (HPCSparseMatrix fields src:216-221; local block as dumped by test/test_dump_matrices.jl:62-71): 1-based
+    `row_partition` / `col_partition`, the sorted global ids `col_indices` of the columns the local rows touch, and
+    the local rows as the CSC of the transposed block (`colptr` over local rows, `rowval` = compressed column index,
+    `nzval`), 1-based like the Julia structs.  Host only; for interop and matrix captures."""
+    assert 0 <= rank < world
+    S = sp.csr_matrix(S)
+    S.sort_indices()
+    rpart, cpart = hpc_partition(S.shape[0], world), hpc_partition(S.shape[1], world)
+    blk = S[rpart[rank] - 1:rpart[rank + 1] - 1]
+    cols = np.unique(blk.indices)
+    return dict(row_partition=rpart, col_partition=cpart, col_indices=(cols + 1).astype(Ti),
+                colptr=(blk.indptr + 1).astype(Ti), rowval=(np.searchsorted(cols, blk.indices) + 1).astype(Ti),
+                nzval=np.array(blk.data, dtype=np.float64), nrows_local=int(blk.shape[0]),
+                ncols_compressed=int(cols.size), has_sorted_rows=True)
+
+
+def hpc_from_local_blocks(blocks) -> sp.csr_matrix:
+    """Inverse of `hpc_local_block`: stack the per-rank blocks (in rank order) back into one scipy CSR."""
+    rpart, cpart = blocks[0]["row_partition"], blocks[0]["col_partition"]
+    rows = []
+    for b in blocks:
+        ci = np.asarray(b["col_indices"], dtype=np.int64)[np.asarray(b["rowval"], dtype=np.int64) - 1] - 1
+        rows.append(sp.csr_matrix((b["nzval"], ci, np.asarray(b["colptr"], dtype=np.int64) - 1),
+                                  shape=(b["nrows_local"], int(cpart[-1]) - 1)))
+    S = sp.vstack(rows, format="csr")
+    assert S.shape[0] == int(rpart[-1]) - 1
+    return S
+
+
 class HPCSparseMatrix:
     """Device CSR matrix (reference HPCSparseMatrix local block, src:216-221).  A host copy of the
     structure is kept for `mpi_to_native` (the reference gathers with SparseMatrixCSC(x), src:371)."""
@@ -243,6 +281,14 @@ class HPCSparseMatrix:
 
     def to_scipy(self):
         return self.host.copy()
+
+    def local_block(self, rank: int, world: int, Ti=np.int32) -> dict:
+        """Rank `rank`'s fields of this matrix in the reference's distributed layout (see `hpc_local_block`)."""
+        return hpc_local_block(self.host, rank, world, Ti)
+
+    @staticmethod
+    def from_local_blocks(blocks, backend: Optional["HPCBackend"] = None) -> "HPCSparseMatrix":
+        return HPCSparseMatrix(hpc_from_local_blocks(blocks), backend)
 
     def __del__(self):
         try:
@@ -593,6 +639,12 @@ class AMG:
         rp, ci = self.hessian_pattern(l)
         Lo = sp.csr_matrix((vals, ci, rp), shape=(N, N))
         return Lo + sp.tril(Lo, -1).T, vals
+
+    def f2_hpc(self, l, s, t) -> HPCSparseMatrix:
+        """The Newton matrix R'HR of level l as an HPCSparseMatrix (what `f2` returns in the reference and what
+        test/test_newton_matrix_compare.jl:33-51 captures); `.local_block(rank, world)` gives the per-rank fields."""
+        H, _ = self.f2(l, s, t)
+        return HPCSparseMatrix(H, self.geometry.x.backend)
 
     def solve_linear(self, l, lower_vals, g, solver="gpu"):
         """MultiGridBarrier.solve(A, b) = A \\ b on the level's fixed pattern: device (default) or host

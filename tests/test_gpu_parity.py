@@ -416,3 +416,22 @@ def test_tiny_meshes_match_oracle(M, kind, L, p, kw):
     z = M.mpi_to_native(sol).z
     assert z.shape == ref.z.shape
     assert np.linalg.norm(z - ref.z) <= 1e-10 * np.linalg.norm(ref.z)
+
+
+def test_newton_matrix_capture_in_reference_layout(M):
+    """SURVEY 8(f)4 / test/test_newton_matrix_compare.jl:33-51: the assembled Newton matrix leaves the library as an
+    HPCSparseMatrix whose per-rank blocks (src:216-221) stack back to the same matrix, and A \\ b on it agrees."""
+    A, Mo, B, z0, c, go = _problem(M, "fem2d", 3, 1.5)
+    l = 2
+    N = A.level_size(l)[0]
+    s = np.zeros(N)
+    H, lower = A.f2(l, s, 1.0)
+    Hm = A.f2_hpc(l, s, 1.0)
+    assert Hm.shape == (N, N) and abs(Hm.to_scipy() - H).max() == 0
+    blocks = [Hm.local_block(r, 4) for r in range(4)]
+    assert blocks[0]["row_partition"][-1] == N + 1 and blocks[0]["colptr"].dtype == np.int32
+    back = M.HPCSparseMatrix.from_local_blocks(blocks)
+    assert abs(back.to_scipy() - H).max() == 0
+    g = A.f1(l, s, 1.0)
+    x = A.solve_linear(l, lower, g)
+    assert rel((back @ M.HPCVector(x)).to_numpy(), g) < 1e-10

@@ -261,3 +261,24 @@ def test_header_is_plain_c_and_links(tmp_path):
                    check=True, capture_output=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert int(out[0]) == 100 and int(out[1]) == len(names)
+
+
+def test_hpc_sparse_on_wire_layout():
+    """per-rank HPCSparseMatrix fields (src:216-221, test/test_dump_matrices.jl:62-71) -- 1-based
+    offsets, compressed sorted column ids, CSR of the local rows -- round-trip to the global matrix."""
+    import scipy.sparse as sp
+    import mgb_amd as M
+    A = sp.csr_matrix(np.array([[1.0, 0, 0, 2], [0, 3, 0, 0], [0, 0, 0, 0], [4, 0, 5, 0], [0, 6, 0, 7]]))
+    b0, b1 = (M.hpc_local_block(A, r, 2) for r in range(2))
+    assert b0["row_partition"].tolist() == [1, 4, 6] and b0["col_partition"].tolist() == [1, 3, 5]
+    assert b0["nrows_local"] == 3 and b0["col_indices"].tolist() == [1, 2, 4] and b0["ncols_compressed"] == 3
+    assert b0["colptr"].tolist() == [1, 3, 4, 4] and b0["rowval"].tolist() == [1, 3, 2] and b0["nzval"].tolist() == [1, 2, 3]
+    assert b1["col_indices"].tolist() == [1, 2, 3, 4] and b1["colptr"].tolist() == [1, 3, 5]
+    assert b1["rowval"].tolist() == [1, 3, 2, 4] and b0["colptr"].dtype == np.int32
+    rng = np.random.default_rng(0)
+    for m, n, P in ((17, 9, 3), (8, 8, 8), (5, 40, 2), (12, 7, 1)):
+        S = sp.random(m, n, density=0.3, random_state=rng, format="csr")
+        blocks = [M.hpc_local_block(S, r, P) for r in range(P)]
+        assert sum(b["nrows_local"] for b in blocks) == m
+        assert all(np.all(np.diff(b["col_indices"]) > 0) for b in blocks)
+        assert abs(M.hpc_from_local_blocks(blocks) - S).max() == 0
