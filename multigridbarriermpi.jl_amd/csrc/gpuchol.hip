@@ -59,6 +59,63 @@ __device__ inline double readlane_f64(double v, int lane) {
 // (zero above the diagonal).
 // Called by every thread of the workgroup (contains a barrier); D must be visible (barrier) before the call.
 // Lo: 32 x LP LDS scratch, distinct from D.
+// the 16 rounds of the in-register factorisation: straight-line code, or (BRK) with an exit test per round
+template <bool BRK>
+__device__ inline void factor_rounds(double (&a)[PB / 2], double* col, int i, int h, bool& bad, int kw) {
+#pragma unroll
+  for (int kk = 0; kk < PB / 2; ++kk) {
+    const int k = 2 * kk, hk = kk & 1, mk = kk >> 1;
+    if (BRK && k >= kw) break;
+    double akk = readlane_f64(a[2 * mk], k + 32 * hk);
+    const double ak1k = readlane_f64(a[2 * mk], k + 1 + 32 * hk);
+    const double ak1k1 = readlane_f64(a[2 * mk + 1], k + 1 + 32 * hk);
+    if (!(akk > 0.0) || !isfinite(akk)) {
+      bad = true;
+      akk = 1.0;
+    }
+    const double rd0 = rsqrt(akk);              // 1 / L[k][k]
+    const double l10 = ak1k * rd0;              // L[k+1][k]
+    double d1 = fma(-l10, l10, ak1k1);
+    if (!(d1 > 0.0) || !isfinite(d1)) {
+      bad = true;
+      d1 = 1.0;
+    }
+    const double rd1 = rsqrt(d1);               // 1 / L[k+1][k+1]
+    if (h == hk) {
+      const double l0 = (i > k) ? a[2 * mk] * rd0 : 0.0;
+      const double l1 = (i > k + 1) ? fma(-l0, l10, a[2 * mk + 1]) * rd1 : 0.0;
+      col[2 * i] = l0;
+      col[2 * i + 1] = l1;
+      a[2 * mk] = (i == k) ? rd0 : l0;
+      a[2 * mk + 1] = (i == k + 1) ? rd1 : l1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const double li0 = col[2 * i], li1 = col[2 * i + 1];
+    if (hk == 0) {      // the pair (k+2, k+3) lives in the h = 1 lanes at the same register slots
+      const double m0 = (h == 1) ? li0 : 0.0, m1 = (h == 1) ? li1 : 0.0;
+      a[2 * mk] = fma(-m1, col[2 * (k + 2) + 1], fma(-m0, col[2 * (k + 2)], a[2 * mk]));
+      a[2 * mk + 1] = fma(-m1, col[2 * (k + 3) + 1], fma(-m0, col[2 * (k + 3)], a[2 * mk + 1]));
+    }
+#pragma unroll
+    for (int m = mk + 1; m < PB / 4; ++m) {
+      const int c = 4 * m + 2 * h;
+      a[2 * m] = fma(-li1, col[2 * c + 1], fma(-li0, col[2 * c], a[2 * m]));
+      a[2 * m + 1] = fma(-li1, col[2 * c + 3], fma(-li0, col[2 * c + 2], a[2 * m + 1]));
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// LEAF (front_leaf, whose second panel has 2..11 columns): (1) leave the rounds at the identity padding, which needs
+// none (bitwise the same result).  The exit test per round costs a full-width block 4 us (measured on front_start /
+// front_step), and 4/8/16-round variants behind one branch made front_single slower whenever two of its workgroups
+// shared a CU, so everything else runs the plain 16 rounds.  (2) Lo is the PACKED lower triangle (row r at
+// r (r + 1) / 2, 528 doubles): with the packed front this is what lets four leaf workgroups share a CU.
+__device__ inline constexpr int lo_packed(int r, int c) { return r * (r + 1) / 2 + c; }
+
+template <bool LEAF = false>
 __device__ void factor_diag_block(const double* D, int kw, double* Lo, double* lp, int* fail, long long* prof) {
   const int tid = threadIdx.x;
   if (tid < 64) {
@@ -73,49 +130,8 @@ __device__ void factor_diag_block(const double* D, int kw, double* Lo, double* l
     }
     bool bad = false;
     double* col = Lo;      // the broadcast line aliases the output block, which is only written after the loop
-#pragma unroll
-    for (int kk = 0; kk < PB / 2; ++kk) {
-      const int k = 2 * kk, hk = kk & 1, mk = kk >> 1;
-      double akk = readlane_f64(a[2 * mk], k + 32 * hk);
-      const double ak1k = readlane_f64(a[2 * mk], k + 1 + 32 * hk);
-      const double ak1k1 = readlane_f64(a[2 * mk + 1], k + 1 + 32 * hk);
-      if (!(akk > 0.0) || !isfinite(akk)) {
-        bad = true;
-        akk = 1.0;
-      }
-      const double rd0 = rsqrt(akk);              // 1 / L[k][k]
-      const double l10 = ak1k * rd0;              // L[k+1][k]
-      double d1 = fma(-l10, l10, ak1k1);
-      if (!(d1 > 0.0) || !isfinite(d1)) {
-        bad = true;
-        d1 = 1.0;
-      }
-      const double rd1 = rsqrt(d1);               // 1 / L[k+1][k+1]
-      if (h == hk) {
-        const double l0 = (i > k) ? a[2 * mk] * rd0 : 0.0;
-        const double l1 = (i > k + 1) ? fma(-l0, l10, a[2 * mk + 1]) * rd1 : 0.0;
-        col[2 * i] = l0;
-        col[2 * i + 1] = l1;
-        a[2 * mk] = (i == k) ? rd0 : l0;
-        a[2 * mk + 1] = (i == k + 1) ? rd1 : l1;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      const double li0 = col[2 * i], li1 = col[2 * i + 1];
-      if (hk == 0) {      // the pair (k+2, k+3) lives in the h = 1 lanes at the same register slots
-        const double m0 = (h == 1) ? li0 : 0.0, m1 = (h == 1) ? li1 : 0.0;
-        a[2 * mk] = fma(-m1, col[2 * (k + 2) + 1], fma(-m0, col[2 * (k + 2)], a[2 * mk]));
-        a[2 * mk + 1] = fma(-m1, col[2 * (k + 3) + 1], fma(-m0, col[2 * (k + 3)], a[2 * mk + 1]));
-      }
-#pragma unroll
-      for (int m = mk + 1; m < PB / 4; ++m) {
-        const int c = 4 * m + 2 * h;
-        a[2 * m] = fma(-li1, col[2 * c + 1], fma(-li0, col[2 * c], a[2 * m]));
-        a[2 * m + 1] = fma(-li1, col[2 * c + 3], fma(-li0, col[2 * c + 2], a[2 * m + 1]));
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
+    if (LEAF) factor_rounds<true>(a, col, i, h, bad, kw);
+    else factor_rounds<false>(a, col, i, h, bad, PB);
     STAMP(6);
     if (bad && tid == 0) atomicOr(fail, 1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -123,14 +139,24 @@ __device__ void factor_diag_block(const double* D, int kw, double* Lo, double* l
 #pragma unroll
     for (int q = 0; q < PB / 2; ++q) {
       const int j = 4 * (q >> 1) + 2 * h + (q & 1);
-      Lo[i * LP + j] = (j <= i) ? a[q] : 0.0;
+      if (LEAF) {
+        if (j <= i) Lo[lo_packed(i, j)] = a[q];
+      } else {
+        Lo[i * LP + j] = (j <= i) ? a[q] : 0.0;
+      }
     }
   }
   __syncthreads();
   if (lp == nullptr) return;      // workgroup-uniform: the caller keeps the factor in Lo only
   for (int idx = tid; idx < PB * PB; idx += blockDim.x) {
-    lp[idx] = Lo[(idx / PB) * LP + idx % PB];               // row-major: lp[32 m + c] = L[m][c]
-    lp[PB * PB + idx] = Lo[(idx % PB) * LP + idx / PB];     // column-major copy: L[m][j] at 32 j + m
+    const int r = idx / PB, c = idx % PB;
+    if (LEAF) {
+      lp[idx] = (c <= r) ? Lo[lo_packed(r, c)] : 0.0;
+      lp[PB * PB + idx] = (r <= c) ? Lo[lo_packed(c, r)] : 0.0;
+    } else {
+      lp[idx] = Lo[r * LP + c];               // row-major: lp[32 m + c] = L[m][c]
+      lp[PB * PB + idx] = Lo[c * LP + r];     // column-major copy: L[m][j] at 32 j + m
+    }
   }
 }
 
@@ -251,14 +277,15 @@ __device__ inline void trsm_row(double (&f)[PB], const double* Lc) {
   }
 }
 
-// the same substitution straight from the ROW-major factor Lo (stride LP; broadcast reads do not care about the
+// the same substitution straight from the row-major PACKED factor Lo (broadcast reads do not care about the
 // stride) with a one-column register window: front_leaf_kernel trades the last LDS latency for occupancy
-__device__ inline void trsm_row_lo(double (&f)[PB], const double* Lo) {
+__device__ inline void trsm_row_lo(double (&f)[PB], const double* Lo, int kw) {
 #pragma unroll
   for (int j = 0; j < PB; ++j) {
+    if ((j & 7) == 0 && j >= kw) break;      // identity padding
     double lc[PB];
 #pragma unroll
-    for (int m = j; m < PB; ++m) lc[m] = Lo[m * LP + j];
+    for (int m = j; m < PB; ++m) lc[m] = Lo[lo_packed(m, j)];
     asm volatile("" ::: "memory");
     const double fj = f[j] * lc[j];
     f[j] = fj;
@@ -574,7 +601,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 // LDS, runs its (at most two) panels -- pivot-block factor, panel rows by in-register substitution, rank-32
 // update on the 4x4 micro-tiles of the tile kernels -- and writes the Schur complement, the rows of L and the
 // pivot blocks back.  One launch replaces front_start + two front_step launches of the widest height of the tree.
-__global__ __launch_bounds__(TB, 3) void front_leaf_kernel(
+__global__ __launch_bounds__(TB, 4) void front_leaf_kernel(
     const GNode* __restrict__ nodes, const int* __restrict__ list, const int* __restrict__ asm_src,
     const int* __restrict__ asm_pos, const double* __restrict__ vals, const int* __restrict__ perm,
     const double* __restrict__ b, double* fronts, double* linv, int* fail, long long* prof) {
@@ -582,11 +609,11 @@ __global__ __launch_bounds__(TB, 3) void front_leaf_kernel(
   STAMP(0);
   const GNode nd = nodes[list[blockIdx.x]];
   const int nf = nd.nf, ld = nf + 1, ns = nd.ns, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  __shared__ __attribute__((aligned(32))) double fixed[2 * PB * LP + PB * LP];      // AT (also D) | Lo
+  __shared__ __attribute__((aligned(32))) double fixed[TS * PB + PB * (PB + 1) / 2];      // AT (also D) | Lo (packed)
   double* Fs = sm;                               // the front, (nf+1)-leading-dimension layout as in HBM
   double* AT = fixed;                            // staging tile of the panel rows (front_step layout), 32 x 64
   double* D = fixed;                             // the pivot block is dead once factored: same storage
-  double* Lo = fixed + 2 * PB * LP;              // row-major factor, reciprocal diagonal
+  double* Lo = fixed + TS * PB;                  // row-major packed factor, reciprocal diagonal
   // packed lower-triangular storage of the front (column j holds rows j..nf): half the LDS of the square layout,
   // which is what lets three workgroups share a CU
   auto P = [ld](int i, int j) { return j * ld - (j * (j - 1)) / 2 + (i - j); };
@@ -609,7 +636,7 @@ __global__ __launch_bounds__(TB, 3) void front_leaf_kernel(
       D[i * LP + j] = (i < kw && j <= i) ? Fs[P(k0 + i, k0 + j)] : 0.0;
     }
     __syncthreads();
-    factor_diag_block(D, kw, Lo, linv + nd.loff + (long long)p * 2 * PB * PB, fail, nullptr);
+    factor_diag_block<true>(D, kw, Lo, linv + nd.loff + (long long)p * 2 * PB * PB, fail, nullptr);
     // the (at most 64) panel rows k1..nf go through the transposed staging tile of the tile kernels, so that the
     // substitution and the rank-32 update are literally the code of front_step (constant LDS strides)
     for (int idx = tid; idx < TS * PB; idx += TB) {
@@ -622,7 +649,7 @@ __global__ __launch_bounds__(TB, 3) void front_leaf_kernel(
       double f[PB];
 #pragma unroll
       for (int m = 0; m < PB; ++m) f[m] = A[m * TS];
-      trsm_row_lo(f, Lo);
+      trsm_row_lo(f, Lo, kw);
 #pragma unroll
       for (int m = 0; m < PB; ++m) A[m * TS] = f[m];
       if (k1 + tid <= nf) {
@@ -641,7 +668,7 @@ __global__ __launch_bounds__(TB, 3) void front_leaf_kernel(
 #pragma unroll
       for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = 0.0;
 #pragma unroll 8
-    for (int q = 0; q < PB; ++q) {
+    for (int q = 0; q < ((kw + 7) & ~7); ++q) {
       const double4 xv = *reinterpret_cast<const double4*>(LI + q * TS);
       const double4 yv = *reinterpret_cast<const double4*>(LJ + q * TS);
       const double x[4] = {xv.x, xv.y, xv.z, xv.w}, y[4] = {yv.x, yv.y, yv.z, yv.w};

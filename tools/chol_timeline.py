@@ -3,8 +3,8 @@
 
   run:      rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 tools/chol_timeline.py run 7 1.0
   analyse:  python3 tools/chol_timeline.py report gpurun_out/tl > gpurun_out/timeline.txt
-The report lists, for the last factor+solve of the run, every dispatch (kernel, workgroups, duration, idle gap
-since the previous dispatch ended) and the per-kernel totals."""
+The report lists every dispatch of a factor+solve chain (kernel, workgroups, duration, idle gap since the previous
+dispatch ended; medians over the chains of the run) and the per-kernel totals."""
 import csv
 import glob
 import os
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(L, p, reps=4, kind="fem2d"):
+def run(L, p, reps=24, kind="fem2d"):
     import numpy as np
     import mgb_amd as M
     geo = getattr(M, kind + "_mpi")(L)
@@ -50,26 +50,33 @@ def report(d):
                 return nm
         return s.split("(")[0][-28:]
 
-    # last factor+solve: from the last factorisation launch that does not follow another one to the last backward_kernel
+    # every factor+solve chain: from a factorisation launch that does not follow another one to the last backward_kernel
+    # before the next chain; chains with the launch count of the last one are kept (the first one also builds the graph)
     ks = [short(r[2]) for r in rows]
     fact = ("front_leaf_kernel", "front_start_kernel", "front_single_kernel", "front_step_kernel")
     starts = [i for i, k in enumerate(ks) if k in fact[:2] and (i == 0 or ks[i - 1] not in fact)]
-    i0 = starts[-1]
-    i1 = max(i for i, k in enumerate(ks) if k == "backward_kernel")
-    seq = rows[i0:i1 + 1]
-    tot, gaps, prev = {}, 0.0, None
+    chains = []
+    for a, b in zip(starts, starts[1:] + [len(rows)]):
+        last = max((i for i in range(a, b) if ks[i] == "backward_kernel"), default=None)
+        if last is not None:
+            chains.append(rows[a:last + 1])
+    chains = [c for c in chains if len(c) == len(chains[-1])][1:] or chains[-1:]
+    med = lambda v: sorted(v)[len(v) // 2]
+    tot, gaps = {}, 0.0
+    print("# %d chains; median per dispatch slot" % len(chains))
     print("# idx kernel workgroups dur_us gap_us")
-    for j, (s, e, name, grid, wg) in enumerate(seq):
-        gap = 0.0 if prev is None else (s - prev) / 1e3
-        prev = e
+    for j in range(len(chains[0])):
+        s, e, name, grid, wg = chains[-1][j]
+        dur = med([(c[j][1] - c[j][0]) / 1e3 for c in chains])
+        gap = 0.0 if j == 0 else med([(c[j][0] - c[j - 1][1]) / 1e3 for c in chains])
         gaps += max(gap, 0.0)
         k = short(name)
         t = tot.setdefault(k, [0, 0.0])
         t[0] += 1
-        t[1] += (e - s) / 1e3
-        print("%4d %-28s %6d %8.2f %7.2f" % (j, k, grid // max(wg, 1), (e - s) / 1e3, gap))
+        t[1] += dur
+        print("%4d %-28s %6d %8.2f %7.2f" % (j, k, grid // max(wg, 1), dur, gap))
     print("# span %.1f us, kernel time %.1f us, idle gaps %.1f us over %d dispatches" %
-          ((seq[-1][1] - seq[0][0]) / 1e3, sum(v[1] for v in tot.values()), gaps, len(seq)))
+          (med([(c[-1][1] - c[0][0]) / 1e3 for c in chains]), sum(v[1] for v in tot.values()), gaps, len(chains[0])))
     for k, (c, t) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
         print("# %-28s %4d launches %9.1f us  avg %7.2f" % (k, c, t, t / c))
 
