@@ -108,14 +108,15 @@ __device__ inline void factor_rounds(double (&a)[PB / 2], double* col, int i, in
   }
 }
 
-// LEAF (front_leaf, whose second panel has 2..11 columns): (1) leave the rounds at the identity padding, which needs
-// none (bitwise the same result).  The exit test per round costs a full-width block 4 us (measured on front_start /
-// front_step), and 4/8/16-round variants behind one branch made front_single slower whenever two of its workgroups
-// shared a CU, so everything else runs the plain 16 rounds.  (2) Lo is the PACKED lower triangle (row r at
-// r (r + 1) / 2, 528 doubles): with the packed front this is what lets four leaf workgroups share a CU.
+// EXIT (front_leaf, whose second panel has 2..11 columns; front_single launches whose fronts have <= 8 pivots): leave
+// the rounds at the identity padding, which needs none (bitwise the same result).  The exit test per round costs a
+// full-width block 4 us (measured on front_start / front_step), and 4/8/16-round variants behind one branch made
+// front_single slower whenever two of its workgroups shared a CU, so everything else runs the plain 16 rounds.
+// PACKED (front_leaf): Lo is the packed lower triangle (row r at r (r + 1) / 2, 528 doubles): with the packed front
+// this is what lets four leaf workgroups share a CU.
 __device__ inline constexpr int lo_packed(int r, int c) { return r * (r + 1) / 2 + c; }
 
-template <bool LEAF = false>
+template <bool EXIT = false, bool PACKED = false>
 __device__ void factor_diag_block(const double* D, int kw, double* Lo, double* lp, int* fail, long long* prof) {
   const int tid = threadIdx.x;
   if (tid < 64) {
@@ -130,7 +131,7 @@ __device__ void factor_diag_block(const double* D, int kw, double* Lo, double* l
     }
     bool bad = false;
     double* col = Lo;      // the broadcast line aliases the output block, which is only written after the loop
-    if (LEAF) factor_rounds<true>(a, col, i, h, bad, kw);
+    if (EXIT) factor_rounds<true>(a, col, i, h, bad, kw);
     else factor_rounds<false>(a, col, i, h, bad, PB);
     STAMP(6);
     if (bad && tid == 0) atomicOr(fail, 1);
@@ -139,7 +140,7 @@ __device__ void factor_diag_block(const double* D, int kw, double* Lo, double* l
 #pragma unroll
     for (int q = 0; q < PB / 2; ++q) {
       const int j = 4 * (q >> 1) + 2 * h + (q & 1);
-      if (LEAF) {
+      if (PACKED) {
         if (j <= i) Lo[lo_packed(i, j)] = a[q];
       } else {
         Lo[i * LP + j] = (j <= i) ? a[q] : 0.0;
@@ -150,7 +151,7 @@ __device__ void factor_diag_block(const double* D, int kw, double* Lo, double* l
   if (lp == nullptr) return;      // workgroup-uniform: the caller keeps the factor in Lo only
   for (int idx = tid; idx < PB * PB; idx += blockDim.x) {
     const int r = idx / PB, c = idx % PB;
-    if (LEAF) {
+    if (PACKED) {
       lp[idx] = (c <= r) ? Lo[lo_packed(r, c)] : 0.0;
       lp[PB * PB + idx] = (r <= c) ? Lo[lo_packed(c, r)] : 0.0;
     } else {
@@ -259,12 +260,14 @@ __global__ __launch_bounds__(TB, 3) void front_start_kernel(const GNode* __restr
 // Lc (LDS, column-major: Lc[32 j + m] = L[m][j], reciprocal diagonal).  Software pipeline: column j+1 of L11
 // is requested (all its LDS reads in flight) before column j is consumed; the empty asm keeps the compiler
 // from sinking the reads back next to their uses.
-__device__ inline void trsm_row(double (&f)[PB], const double* Lc) {
+template <bool EXIT = false>
+__device__ inline void trsm_row(double (&f)[PB], const double* Lc, int kw = PB) {
   double lc[2][PB];
 #pragma unroll
   for (int m = 0; m < PB; ++m) lc[0][m] = Lc[m];
 #pragma unroll
   for (int j = 0; j < PB; ++j) {
+    if (EXIT && (j & 7) == 0 && j >= kw) break;      // identity padding
     if (j + 1 < PB) {
 #pragma unroll
       for (int m = (j + 1) & ~1; m < PB; ++m) lc[(j + 1) & 1][m] = Lc[(j + 1) * PB + m];
@@ -448,6 +451,9 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 // 64x32 panel blocks, and its C tile, each as child0 + child1 contribution through the inverse index maps, plus
 // the assembled matrix entries and the right-hand side (which only live in pivot columns).  Tile (0,0) publishes
 // the pivot block; the tj == 0 tiles the mirrored rows of L.
+// NARROW: launches whose fronts have at most 8 pivots skip the identity padding in the factor, the substitution,
+// the update and the gather of the panel columns.
+template <bool NARROW>
 __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void front_single_kernel(
     const SingleTile* __restrict__ tiles, const int* __restrict__ pinv,
     const int* __restrict__ asm_src, const int* __restrict__ asm_pos, const double* __restrict__ vals,
@@ -504,8 +510,11 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int q = qg * 8 + u;
-      vi[u] = child(rowI[0][r], piv[0][q], rowI[1][r], piv[1][q]);
-      vj[u] = diag ? 0.0 : child(rowJ[0][r], piv[0][q], rowJ[1][r], piv[1][q]);
+      vi[u] = vj[u] = 0.0;
+      if (!NARROW || qg == 0) {      // wave-uniform
+        vi[u] = child(rowI[0][r], piv[0][q], rowI[1][r], piv[1][q]);
+        if (!diag) vj[u] = child(rowJ[0][r], piv[0][q], rowJ[1][r], piv[1][q]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -547,7 +556,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   if (nf >= r0 && nf < r0 + TS)
     for (int q = tid; q < ns; q += TB) ATI[q * TS + tile_pos(nf - r0)] += b[perm[t.first + q]];
   __syncthreads();
-  factor_diag_block(D, kw, Lo, (t.ti == 0 && t.tj == 0) ? linv + t.loff : nullptr, fail, nullptr);
+  factor_diag_block<NARROW>(D, kw, Lo, (t.ti == 0 && t.tj == 0) ? linv + t.loff : nullptr, fail, nullptr);
   for (int idx = tid; idx < PB * PB; idx += TB) Lc[idx] = Lo[(idx % PB) * LP + idx / PB];     // Lc[32 j + m] = L[m][j]
   __syncthreads();
   STAMP(2);
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     double f[PB];
 #pragma unroll
     for (int m = 0; m < PB; ++m) f[m] = A[m * TS];
-    trsm_row(f, Lc);
+    trsm_row<NARROW>(f, Lc, kw);
 #pragma unroll
     for (int m = 0; m < PB; ++m) A[m * TS] = f[m];
     if (t.tj == 0 && tid < TS && r0 + r <= nf) {
@@ -577,7 +586,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #pragma unroll
     for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = 0.0;
 #pragma unroll 8
-  for (int q = 0; q < PB; ++q) {
+  for (int q = 0; q < (NARROW ? 8 : PB); ++q) {
     const double4 xv = *reinterpret_cast<const double4*>(LI + q * TS);
     const double4 yv = *reinterpret_cast<const double4*>(LJ + q * TS);
     const double x[4] = {xv.x, xv.y, xv.z, xv.w}, y[4] = {yv.x, yv.y, yv.z, yv.w};
@@ -636,7 +645,7 @@ __global__ __launch_bounds__(TB, 4) void front_leaf_kernel(
       D[i * LP + j] = (i < kw && j <= i) ? Fs[P(k0 + i, k0 + j)] : 0.0;
     }
     __syncthreads();
-    factor_diag_block<true>(D, kw, Lo, linv + nd.loff + (long long)p * 2 * PB * PB, fail, nullptr);
+    factor_diag_block<true, true>(D, kw, Lo, linv + nd.loff + (long long)p * 2 * PB * PB, fail, nullptr);
     // the (at most 64) panel rows k1..nf go through the transposed staging tile of the tile kernels, so that the
     // substitution and the rank-32 update are literally the code of front_step (constant LDS strides)
     for (int idx = tid; idx < TS * PB; idx += TB) {
@@ -969,6 +978,7 @@ void GpuChol::build(const MfChol& sym) {
       all_pivots = all_pivots && nodes[t].ns >= 1;      // a pass-through front (ns = 0) needs front_start to copy it
     }
     hp.single = single_ok && max_ns <= PB && any_child && all_pivots;
+    hp.narrow = hp.single && max_ns <= 8;
     // front_start jobs
     hp.start.ofs = (int)starts.size();
     hp.start_bytes = 0;
@@ -1162,7 +1172,7 @@ void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, d
     }
     if (hp.single) {
       if (tm) tm->begin(st, KC_CHOL_SINGLE, hp.start_bytes + hp.step_bytes[0]);
-      hipLaunchKernelGGL(front_single_kernel, dim3(hp.single_tiles.cnt), dim3(TB), 0, st, d_singles_ + hp.single_tiles.ofs, d_pinv_,
+      hipLaunchKernelGGL(hp.narrow ? front_single_kernel<true> : front_single_kernel<false>, dim3(hp.single_tiles.cnt), dim3(TB), 0, st, d_singles_ + hp.single_tiles.ofs, d_pinv_,
                          d_asm_src_, d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_fronts_, d_linv_, d_fail_,
                          d_prof_ ? d_prof_ + 8 * (nprof++) : nullptr);
       if (tm) tm->end(st);

@@ -129,6 +129,7 @@ class GpuChol {
     int max_nf;
     bool split;      // backward: rectangular part in its own multi-workgroup launch
     bool single;     // every front has one panel: front_single replaces front_start + front_step
+    bool narrow = false; // single && at most 8 pivots per front
     bool leaf = false;   // small childless fronts: front_leaf does the whole front in one workgroup
   };
   std::vector<HeightPlan> plan_;
