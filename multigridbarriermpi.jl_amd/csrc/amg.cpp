@@ -482,12 +482,19 @@ void Amg::dev_apply(Level& lv, const double* s_dev, double* dz) {
   timer_.end(ctx_.stream);
 }
 
+// bytes of one fused objective evaluation (trial_f0_kernel): the SpMV of B with its Dz0 read and Dz write, then
+// c, w and the cone distances; Dz itself never comes back from memory
+double Amg::trial_bytes(const Level& lv, bool with_ref) const {
+  return csr_bytes(lv.B.view, true) + (double)n_ * (P_.K + 1 + P_.ncones * (with_ref ? 2 : 1)) * 8;
+}
+
 double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts, const double* phi_ref, double* phi_out,
-                   double* dz) {
-  dev_apply(lv, s_dev, dz);
-  timer_.begin(ctx_.stream, KC_F0, (double)n_ * (2 * P_.K + 2 + (phi_ref ? 1 : 0)) * 8);
+                   double* dz, double alpha, const double* nstep, double* s_out) {
+  // objective at x = s_dev + alpha * nstep (x = s_dev without nstep), Dz(x) left in dz: ONE launch (+ the final sum).
   // phi_ref == nullptr: start of a Newton solve (records phi of the iterate); otherwise a line-search trial
-  launch_barrier_f0(ctx_.stream, n_, P_, dz, w_.p, c_.p, phi_ref, kFracToBoundary, phi_out, partials_.p, scal_.p);
+  timer_.begin(ctx_.stream, KC_F0, trial_bytes(lv, phi_ref != nullptr));
+  launch_trial_f0(ctx_.stream, lv.B.view, n_, P_, s_dev, alpha, nstep, s_out, Dz0_.p, dz, w_.p, c_.p, phi_ref,
+                  kFracToBoundary, phi_out, partials_.p, scal_.p);
   timer_.end(ctx_.stream);
   ctx_.allreduce_sum(scal_.p, 2);      // sharded: +inf (a row left the cone on some rank) survives the sum
   hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
@@ -523,11 +530,10 @@ static const double kBeta = 0.5, kArmijo = 0.1, kMinStep = 1e-8;      // oracle 
 
 // enqueue (no host sync): T.s = s - step * nstep, f0 there -> host slot h_scal_[4 + 2 slot .. +1]
 void Amg::enqueue_trial(Level& lv, Trial& T, double step, int slot) {
-  launch_waxpby(ctx_.stream, lv.plan.N, lv.s.p, -step, lv.nstep.p, T.s);
-  dev_apply(lv, T.s, T.dz);
   double* out = scal_.p + 4 + 2 * slot;
-  timer_.begin(ctx_.stream, KC_F0, (double)n_ * (2 * P_.K + 3) * 8);
-  launch_barrier_f0(ctx_.stream, n_, P_, T.dz, w_.p, c_.p, phi_cur_.p, kFracToBoundary, T.phi, partials_.p, out);
+  timer_.begin(ctx_.stream, KC_F0, trial_bytes(lv, true));
+  launch_trial_f0(ctx_.stream, lv.B.view, n_, P_, lv.s.p, -step, lv.nstep.p, T.s, Dz0_.p, T.dz, w_.p, c_.p, phi_cur_.p,
+                  kFracToBoundary, T.phi, partials_.p, out);
   timer_.end(ctx_.stream);
   ctx_.allreduce_sum(out, 2);
   T.step = step;      // the caller copies scal_[3..7] (inc + both trials) back in one transfer
@@ -656,8 +662,7 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
   // objective at s - step * nstep in T's buffers (served from the speculative evaluation when it matches)
   auto eval = [&](Trial& X, double step) {
     if (X.valid && X.step == step) return X.y;
-    launch_waxpby(ctx_.stream, N, lv.s.p, -step, lv.nstep.p, X.s);
-    X.y = dev_f0(lv, X.s, t, nullptr, phi_cur_.p, X.phi, X.dz);
+    X.y = dev_f0(lv, lv.s.p, t, nullptr, phi_cur_.p, X.phi, X.dz, -step, lv.nstep.p, X.s);
     st.n_f0++;
     X.step = step;
     X.valid = true;

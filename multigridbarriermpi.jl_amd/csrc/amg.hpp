@@ -245,8 +245,11 @@ class Amg {
   void ensure_chol(Level& lv);    // factorisation structures, built on first solve
   void refresh_dz0();
   void dev_apply(Level& lv, const double* s_dev, double* dz);     // dz = Dz0 + B s
+  // objective at x = s_dev + alpha * nstep (nstep nullable: x = s_dev); leaves D(z + R x) in dz and x in s_out
+  // (nullable) -- one fused launch (trial_f0_kernel)
   double dev_f0(Level& lv, const double* s_dev, double t, double* parts, const double* phi_ref, double* phi_out,
-                double* dz);      // evaluates D at s into dz first
+                double* dz, double alpha = 0.0, const double* nstep = nullptr, double* s_out = nullptr);
+  double trial_bytes(const Level& lv, bool with_ref) const;
   double dev_f1(Level& lv, const double* dz, double t, double* g_out);   // gradient from the Dz of the point; returns |g|
   // one line-search trial point s - step * nstep with its scratch buffers and (cached) objective value
   struct Trial {

@@ -624,7 +624,7 @@ __global__ __launch_bounds__(TB, 4) void front_leaf_kernel(
   double* D = fixed;                             // the pivot block is dead once factored: same storage
   double* Lo = fixed + TS * PB;                  // row-major packed factor, reciprocal diagonal
   // packed lower-triangular storage of the front (column j holds rows j..nf): half the LDS of the square layout,
-  // which is what lets three workgroups share a CU
+  // which (with the packed pivot-block factor) is what lets four workgroups share a CU
   auto P = [ld](int i, int j) { return j * ld - (j * (j - 1)) / 2 + (i - j); };
   const int total = nf * ld - (nf * (nf - 1)) / 2;
   double* F = fronts + nd.off;

@@ -10,6 +10,7 @@
 // a9 dot/.* / column extract (test/test_column_extract.jl:50-66).
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <cmath>
 
 namespace mgb {
@@ -115,6 +116,8 @@ __global__ __launch_bounds__(kBlock) void final_sum_kernel(int nparts, int nout,
 }
 
 // ---------------------------------------------------------------- barrier
+constexpr int kMaxK = 8;      // rows of D (capi.cpp rejects larger problems for the barrier kernels)
+
 struct Cone {
   double q[3];
   double s, phi, sa;  // sa = s^a
@@ -176,11 +179,116 @@ __global__ __launch_bounds__(kBlock) void barrier_f0_kernel(int n, BarrierParams
   }
 }
 
+
+// One objective evaluation of the line search in ONE launch (reference: f0 = apply_D, then map_rows of the barrier,
+// then two dots -- SURVEY 8a a3/a4): x = s + alpha * nstep is formed on the fly (and written to s_out for the
+// caller that accepts the trial), Dz = Dz0 + B x is computed for 64 nodes (64 K consecutive rows of B) per pass with
+// the lane layout and summation order of spmv_kernel<G> -- bitwise the same Dz -- kept in LDS and written once, and
+// the barrier terms of those nodes are accumulated straight from LDS.  Saves the waxpby and barrier_f0 launches and
+// the re-read of Dz; bytes = spmv(B) + n (K + 2 + ncones [+ ncones]) 8.
+constexpr int kTrialNodes = 64;
+template <int G>
+__global__ __launch_bounds__(kBlock) void trial_f0_kernel(int n, int N, BarrierParams P, const int* __restrict__ rowptr,
+                                                           const int* __restrict__ colidx, const double* __restrict__ vals,
+                                                           const double* __restrict__ s, double alpha,
+                                                           const double* __restrict__ nstep, double* s_out,
+                                                           const double* __restrict__ Dz0, double* Dz,
+                                                           const double* __restrict__ w, const double* __restrict__ c,
+                                                           const double* __restrict__ phi_ref, double frac,
+                                                           double* __restrict__ phi_out, double* partials) {
+  __shared__ double lds[kBlock / 64];
+  __shared__ double dzs[kTrialNodes * kMaxK];
+  constexpr int GR = kBlock / G;      // rows per pass
+  const int K = P.K, lane = threadIdx.x % G, grp = threadIdx.x / G;
+  if (s_out)
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < N; i += (long long)gridDim.x * kBlock)
+      s_out[i] = s[i] + alpha * nstep[i];
+  auto xval = [&](int j) { return nstep ? s[j] + alpha * nstep[j] : s[j]; };
+  double accF = 0.0, accL = 0.0;
+  const int nchunks = (n + kTrialNodes - 1) / kTrialNodes;
+  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int q0 = ch * kTrialNodes, nq = min(kTrialNodes, n - q0), nrows = nq * K;
+    const long long r0 = (long long)q0 * K;
+    for (int rr0 = grp; rr0 < nrows; rr0 += kSpmvU * GR) {
+      int b[kSpmvU], e[kSpmvU], ci[kSpmvU];
+      double acc[kSpmvU], base[kSpmvU], va[kSpmvU];
+#pragma unroll
+      for (int u = 0; u < kSpmvU; ++u) {
+        const int rr = rr0 + u * GR;
+        const bool ok = rr < nrows;
+        b[u] = ok ? rowptr[r0 + rr] : 0;
+        e[u] = ok ? rowptr[r0 + rr + 1] : 0;
+        base[u] = (ok && lane == 0) ? Dz0[r0 + rr] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kSpmvU; ++u) {
+        const int k = b[u] + lane;
+        const bool in = k < e[u];
+        ci[u] = in ? colidx[k] : -1;
+        va[u] = in ? vals[k] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kSpmvU; ++u) acc[u] = (ci[u] >= 0) ? va[u] * xval(ci[u]) : 0.0;
+#pragma unroll
+      for (int u = 0; u < kSpmvU; ++u)
+        for (int k = b[u] + lane + G; k < e[u]; k += G) acc[u] += vals[k] * xval(colidx[k]);
+#pragma unroll
+      for (int u = 0; u < kSpmvU; ++u) {
+        double a = acc[u];
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) a += __shfl_down(a, o, G);
+        const int rr = rr0 + u * GR;
+        if (lane == 0 && rr < nrows) {
+          const double v = base[u] + a;
+          Dz[r0 + rr] = v;
+          dzs[rr] = v;
+        }
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nq) {
+      const long long q = q0 + threadIdx.x;
+      const double* dz = dzs + threadIdx.x * K;
+      const double* cq = c + q * K;
+      const double wq = w[q];
+      double F = 0.0;
+      for (int ci = 0; ci < P.ncones; ++ci) {
+        Cone k = load_cone(P.cone[ci], dz);
+        if (phi_ref && !(k.phi >= frac * phi_ref[q * P.ncones + ci])) k.ok = false;
+        if (phi_out) phi_out[q * P.ncones + ci] = k.phi;
+        F += k.ok ? (-log(k.phi) - P.cone[ci].mu * log(k.s)) : INFINITY;
+      }
+      accF += wq * F;
+      double lin = 0.0;
+      for (int j = 0; j < K; ++j) lin += cq[j] * dz[j];
+      accL += wq * lin;
+    }
+    __syncthreads();
+  }
+  double rF = block_sum(accF, lds);
+  double rL = block_sum(accL, lds);
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = rF;
+    partials[2 * blockIdx.x + 1] = rL;
+  }
+}
+
+inline int trial_grid(int n) {
+  const int b = (n + kTrialNodes - 1) / kTrialNodes;
+  return b < 1 ? 1 : (b > kMaxBlocks ? kMaxBlocks : b);
+}
+
+template <int G>
+void trial_launch(hipStream_t st, const DevCsr& B, int n, const BarrierParams& P, const double* s, double alpha,
+                  const double* nstep, double* s_out, const double* Dz0, double* Dz, const double* w, const double* c,
+                  const double* phi_ref, double frac, double* phi_out, double* partials) {
+  hipLaunchKernelGGL(trial_f0_kernel<G>, dim3(trial_grid(n)), dim3(kBlock), 0, st, n, B.cols, P, B.rowptr, B.colidx, B.vals, s,
+                     alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials);
+}
+
 // register-only helpers: the D-row indices of a cone are run-time data, so rows are picked / updated with
 // unrolled selects instead of dynamically indexed local arrays (which would live in scratch) or global
 // read-modify-writes (which serialise on memory latency)
-constexpr int kMaxK = 8;      // rows of D (capi.cpp rejects larger problems for the barrier kernels)
-
 __device__ inline double pick3(const double (&q)[3], int i) { return i == 0 ? q[0] : (i == 1 ? q[1] : q[2]); }
 
 __global__ __launch_bounds__(kBlock) void barrier_f1_kernel(int n, BarrierParams P, const double* __restrict__ Dz,
@@ -308,7 +416,22 @@ void launch_waxpby(hipStream_t st, int n, const double* x, double alpha, const d
   hipLaunchKernelGGL(waxpby_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, x, alpha, y, out);
 }
 
-int f0_blocks(int n) { return grid_for(n); }
+int f0_blocks(int n) { return std::max(grid_for(n), trial_grid(n)); }
+
+void launch_trial_f0(hipStream_t st, const DevCsr& B, int n, BarrierParams P, const double* s, double alpha,
+                     const double* nstep, double* s_out, const double* Dz0, double* Dz, const double* w, const double* c,
+                     const double* phi_ref, double frac, double* phi_out, double* partials, double* out2) {
+  switch (B.group) {
+    case 1: trial_launch<1>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials); break;
+    case 2: trial_launch<2>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials); break;
+    case 4: trial_launch<4>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials); break;
+    case 8: trial_launch<8>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials); break;
+    case 16: trial_launch<16>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials); break;
+    case 32: trial_launch<32>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials); break;
+    default: trial_launch<64>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials); break;
+  }
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, trial_grid(n), 2, partials, out2);
+}
 
 void launch_barrier_f0(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
                        const double* phi_ref, double frac, double* phi_out, double* partials, double* out2) {

@@ -54,6 +54,11 @@ int f0_blocks(int n);
 // (nullable, n x ncones): per-row cone distances s^(2/p) - |q|^2 of this evaluation.
 void launch_barrier_f0(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
                        const double* phi_ref, double frac, double* phi_out, double* partials, double* out2);
+// the same two sums for x = s + alpha * nstep (nstep nullable: x = s) in one launch: Dz = Dz0 + B x is written on the
+// way (B: the n K x N apply_D matrix of the level, rows node-major), s_out (nullable) receives x
+void launch_trial_f0(hipStream_t st, const DevCsr& B, int n, BarrierParams P, const double* s, double alpha,
+                     const double* nstep, double* s_out, const double* Dz0, double* Dz, const double* w, const double* c,
+                     const double* phi_ref, double frac, double* phi_out, double* partials, double* out2);
 // v[q,k] = w_q (dF/dDz_k + t c[q,k])
 void launch_barrier_f1(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
                        double t, double* v);
