@@ -151,8 +151,9 @@ int mgb_amg_sol_get(mgb_amg a, long long* its /* L x nt col-major */, double* ts
  *         chol_front_start, chol_front_step, chol_backward_rect, chol_backward, chol_front_single */
 int mgb_amg_sol_kernels(mgb_amg a, double* ms11, double* bytes11, long long* launches11);
 /* per-kernel device timings (HIP events on the context stream), ms and algorithmic bytes per launch:
- * order = apply_D, barrier_f2, hessian_assemble, barrier_f1, restrict, barrier_f0 */
-int mgb_amg_time_kernels(mgb_amg a, int level, int reps, double* ms6, double* bytes6);
+ * order = apply_D, barrier_f2, hessian_assemble, barrier_f1, restrict, barrier_f0, trial_f0 (the fused trial point +
+ * apply_D + barrier_f0 launch every objective evaluation of the solve uses) */
+int mgb_amg_time_kernels(mgb_amg a, int level, int reps, double* ms7, double* bytes7);
 
 /* ---- host-only symbolic helpers (no GPU needed; used by the CPU test-suite) ----------------- */
 typedef struct mgb_plan_s* mgb_plan;  /* symbolic products of one level: R, B=D*R, B', Hessian plan T */

@@ -686,10 +686,10 @@ class AMG:
                     "chol_front_start", "chol_front_step", "chol_backward_rect", "chol_backward", "chol_front_single")
 
     def time_kernels(self, l, reps=50):
-        ms = np.empty(6)
-        by = np.empty(6)
+        ms = np.empty(7)
+        by = np.empty(7)
         call("mgb_amg_time_kernels", self.handle, l, reps, dptr(ms), dptr(by))
-        names = ("apply_D", "barrier_f2", "hessian_assemble", "barrier_f1", "restrict", "barrier_f0")
+        names = ("apply_D", "barrier_f2", "hessian_assemble", "barrier_f1", "restrict", "barrier_f0", "trial_f0")
         return {k: dict(ms=float(m), bytes=float(b)) for k, m, b in zip(names, ms, by)}
 
     def __del__(self):

@@ -2,6 +2,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 
 namespace mgb {
@@ -288,6 +289,7 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
 Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierParams& P)
     : ctx_(ctx), n_(g.n), S_((int)spec.state_variables.size()), P_(P), spec_(spec) {
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
+  if (const char* e = std::getenv("MGB_FUSED_TRIAL_ROWS")) fused_trial_rows_ = std::atoi(e);      // 0: never fuse
   if (P.K != (int)spec.D.size()) throw std::runtime_error("amg: barrier K != number of D rows");
   if (P.ncones < 1 || P.ncones > 2) throw std::runtime_error("amg: barrier supports 1 or 2 cones");
   if (P.K > 8) throw std::runtime_error("amg: the barrier kernels support at most 8 rows of D");
@@ -488,14 +490,34 @@ double Amg::trial_bytes(const Level& lv, bool with_ref) const {
   return csr_bytes(lv.B.view, true) + (double)n_ * (P_.K + 1 + P_.ncones * (with_ref ? 2 : 1)) * 8;
 }
 
+// Launch-bound meshes (every 64-node chunk gets its own workgroup: n <= 131 072, fem2d L <= 7) evaluate the objective
+// in ONE fused launch; beyond that the three bandwidth-shaped kernels are faster (at fem2d L=9 the fused kernel
+// reaches 24 % of HBM peak, apply_D + barrier_f0 43 % each) and launch gaps no longer matter.
+void Amg::enqueue_f0(Level& lv, const double* s_dev, double alpha, const double* nstep, double* s_out, double* dz,
+                     const double* phi_ref, double* phi_out, double* out2) {
+  if (n_ <= fused_trial_rows_) {
+    timer_.begin(ctx_.stream, KC_F0, trial_bytes(lv, phi_ref != nullptr));
+    launch_trial_f0(ctx_.stream, lv.B.view, n_, P_, s_dev, alpha, nstep, s_out, Dz0_.p, dz, w_.p, c_.p, phi_ref,
+                    kFracToBoundary, phi_out, partials_.p, out2);
+    timer_.end(ctx_.stream);
+    return;
+  }
+  const double* x = s_dev;
+  if (nstep) {
+    launch_waxpby(ctx_.stream, lv.plan.N, s_dev, alpha, nstep, s_out);
+    x = s_out;
+  }
+  dev_apply(lv, x, dz);
+  timer_.begin(ctx_.stream, KC_F0, (double)n_ * (2 * P_.K + 2 + (phi_ref ? 1 : 0)) * 8);
+  launch_barrier_f0(ctx_.stream, n_, P_, dz, w_.p, c_.p, phi_ref, kFracToBoundary, phi_out, partials_.p, out2);
+  timer_.end(ctx_.stream);
+}
+
 double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts, const double* phi_ref, double* phi_out,
                    double* dz, double alpha, const double* nstep, double* s_out) {
-  // objective at x = s_dev + alpha * nstep (x = s_dev without nstep), Dz(x) left in dz: ONE launch (+ the final sum).
+  // objective at x = s_dev + alpha * nstep (x = s_dev without nstep), Dz(x) left in dz.
   // phi_ref == nullptr: start of a Newton solve (records phi of the iterate); otherwise a line-search trial
-  timer_.begin(ctx_.stream, KC_F0, trial_bytes(lv, phi_ref != nullptr));
-  launch_trial_f0(ctx_.stream, lv.B.view, n_, P_, s_dev, alpha, nstep, s_out, Dz0_.p, dz, w_.p, c_.p, phi_ref,
-                  kFracToBoundary, phi_out, partials_.p, scal_.p);
-  timer_.end(ctx_.stream);
+  enqueue_f0(lv, s_dev, alpha, nstep, s_out, dz, phi_ref, phi_out, scal_.p);
   ctx_.allreduce_sum(scal_.p, 2);      // sharded: +inf (a row left the cone on some rank) survives the sum
   hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
   sync_collect("sync f0");
@@ -531,10 +553,7 @@ static const double kBeta = 0.5, kArmijo = 0.1, kMinStep = 1e-8;      // oracle 
 // enqueue (no host sync): T.s = s - step * nstep, f0 there -> host slot h_scal_[4 + 2 slot .. +1]
 void Amg::enqueue_trial(Level& lv, Trial& T, double step, int slot) {
   double* out = scal_.p + 4 + 2 * slot;
-  timer_.begin(ctx_.stream, KC_F0, trial_bytes(lv, true));
-  launch_trial_f0(ctx_.stream, lv.B.view, n_, P_, lv.s.p, -step, lv.nstep.p, T.s, Dz0_.p, T.dz, w_.p, c_.p, phi_cur_.p,
-                  kFracToBoundary, T.phi, partials_.p, out);
-  timer_.end(ctx_.stream);
+  enqueue_f0(lv, lv.s.p, -step, lv.nstep.p, T.s, T.dz, phi_cur_.p, T.phi, out);
   ctx_.allreduce_sum(out, 2);
   T.step = step;      // the caller copies scal_[3..7] (inc + both trials) back in one transfer
 }
@@ -939,6 +958,11 @@ Amg::KernelTimes Amg::time_kernels(int l, int reps) {
     launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, phi_cur_.p, 0.0, phi_trial_.p, partials_.p, scal_.p);
   });
   kt.f0_bytes = n * (2 * K + 3) * 8;
+  kt.trial_ms = timeit([&] {      // the fused objective evaluation the solve actually runs
+    launch_trial_f0(ctx_.stream, lv.B.view, n_, P_, lv.s.p, -0.5, lv.s.p, lv.s_trial.p, Dz0_.p, DzA_.p, w_.p, c_.p,
+                    phi_cur_.p, 0.0, phi_trial_.p, partials_.p, scal_.p);
+  });
+  kt.trial_bytes = trial_bytes(lv, true);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return kt;

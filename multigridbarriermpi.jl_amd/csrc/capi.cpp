@@ -668,14 +668,14 @@ int mgb_amg_sol_kernels(mgb_amg a, double* ms11, double* bytes11, long long* lau
     }
   });
 }
-int mgb_amg_time_kernels(mgb_amg a, int level, int reps, double* ms6, double* bytes6) {
+int mgb_amg_time_kernels(mgb_amg a, int level, int reps, double* ms7, double* bytes7) {
   return guard([&] {
-    need(a && ms6 && bytes6 && reps > 0 && level >= 0 && level < a->amg->L(), "time_kernels: bad arguments");
+    need(a && ms7 && bytes7 && reps > 0 && level >= 0 && level < a->amg->L(), "time_kernels: bad arguments");
     Amg::KernelTimes k = a->amg->time_kernels(level, reps);
-    const double ms[6] = {k.apply_ms, k.f2_ms, k.assemble_ms, k.f1_ms, k.restrict_ms, k.f0_ms};
-    const double by[6] = {k.apply_bytes, k.f2_bytes, k.assemble_bytes, k.f1_bytes, k.restrict_bytes, k.f0_bytes};
-    std::copy(ms, ms + 6, ms6);
-    std::copy(by, by + 6, bytes6);
+    const double ms[7] = {k.apply_ms, k.f2_ms, k.assemble_ms, k.f1_ms, k.restrict_ms, k.f0_ms, k.trial_ms};
+    const double by[7] = {k.apply_bytes, k.f2_bytes, k.assemble_bytes, k.f1_bytes, k.restrict_bytes, k.f0_bytes, k.trial_bytes};
+    std::copy(ms, ms + 7, ms7);
+    std::copy(by, by + 7, bytes7);
   });
 }
 

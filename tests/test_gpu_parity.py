@@ -435,3 +435,29 @@ def test_newton_matrix_capture_in_reference_layout(M):
     g = A.f1(l, s, 1.0)
     x = A.solve_linear(l, lower, g)
     assert rel((back @ M.HPCVector(x)).to_numpy(), g) < 1e-10
+
+
+def test_fused_and_separate_objective_kernels_agree(M, monkeypatch):
+    """The line search evaluates f0 with one fused launch on launch-bound meshes and with waxpby + apply_D + barrier_f0
+    beyond (csrc/amg.cpp: enqueue_f0); Dz is bitwise the same, the sums differ in summation order only."""
+    zf = M.mpi_to_native(M.fem2d_mpi_solve(L=4, p=1.0)).z
+    monkeypatch.setenv("MGB_FUSED_TRIAL_ROWS", "0")
+    sol = M.fem2d_mpi_solve(L=4, p=1.0)
+    zs = M.mpi_to_native(sol).z
+    assert rel(zs, zf) < ZTOL
+    A = M.AMG(M.fem2d_mpi(3), p=1.5)
+    go = O.fem2d(3)
+    Mo = O.amg(go)
+    z0 = O.map_rows(lambda xi: O.DEFAULT_G[2](xi), Mo.x).reshape(-1, order="F")
+    c = O.map_rows(lambda xi: O.DEFAULT_F[2](xi), Mo.x)
+    A.set_c(c)
+    A.set_z(z0)
+    s = np.zeros(A.level_size(2)[0])
+    y_sep = A.f0(2, s, 2.0)
+    monkeypatch.delenv("MGB_FUSED_TRIAL_ROWS")
+    B = M.AMG(M.fem2d_mpi(3), p=1.5)
+    B.set_c(c)
+    B.set_z(z0)
+    y_fused = B.f0(2, s, 2.0)
+    assert abs(y_sep - y_fused) <= 1e-13 * abs(y_fused)
+    assert np.array_equal(A.apply_D(2, s), B.apply_D(2, s))
