@@ -250,7 +250,7 @@ class Amg {
   double dev_f0(Level& lv, const double* s_dev, double t, double* parts, const double* phi_ref, double* phi_out,
                 double* dz, double alpha = 0.0, const double* nstep = nullptr, double* s_out = nullptr);
   double trial_bytes(const Level& lv, bool with_ref) const;
-  int fused_trial_rows_ = 64 * 2048;      // trial_f0_kernel while every 64-node chunk has its own workgroup (env MGB_FUSED_TRIAL_ROWS)
+  int fused_trial_rows_ = 64 * 2048;      // trial_f0_kernel on launch-bound meshes (env MGB_FUSED_TRIAL_ROWS)
   void enqueue_f0(Level& lv, const double* s_dev, double alpha, const double* nstep, double* s_out, double* dz,
                   const double* phi_ref, double* phi_out, double* out2);      // no host sync
   double dev_f1(Level& lv, const double* dz, double t, double* g_out);   // gradient from the Dz of the point; returns |g|
