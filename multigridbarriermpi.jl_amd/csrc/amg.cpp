@@ -529,7 +529,22 @@ double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts, cons
 }
 
 // gradient at s into g_out (device); returns |g|_2 (non-finite if any entry is)
-double Amg::dev_f1(Level& lv, const double* dz, double t, double* g_out) {
+// Hessian values of the point whose Dz is dz: Y = w F2(Dz), avals = T vec(Y) (summed over the row blocks when sharded)
+void Amg::enqueue_f2_assemble(Level& lv, const double* dz, SolveStats& st) {
+  timer_.begin(ctx_.stream, KC_F2, (double)n_ * (P_.K + 1 + P_.nY()) * 8);
+  launch_barrier_f2(ctx_.stream, n_, P_, dz, w_.p, Y_.p);
+  timer_.end(ctx_.stream);
+  timer_.begin(ctx_.stream, KC_ASSEMBLE, csr_bytes(lv.T.view, false));
+  launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
+  timer_.end(ctx_.stream);
+  ctx_.allreduce_sum(lv.avals.p, lv.plan.Apat.nnz());      // sharded: every rank then factors the same replicated matrix
+  st.n_f2++;
+}
+
+// pre (nullable): the caller expects this point to become the next iterate -- its Hessian values are assembled
+// BEHIND the gradient while the host waits only for |g| (an event after the scalar's copy), so the GPU works through
+// the host's round trip; *pre is set to dz to tell dev_f2_solve that avals already hold this point's Hessian.
+double Amg::dev_f1(Level& lv, const double* dz, double t, double* g_out, SolveStats* st, const double** pre) {
   timer_.begin(ctx_.stream, KC_F1, (double)n_ * (3 * P_.K + 1) * 8);
   launch_barrier_f1(ctx_.stream, n_, P_, dz, w_.p, c_.p, t, v_.p);
   timer_.end(ctx_.stream);
@@ -542,7 +557,16 @@ double Amg::dev_f1(Level& lv, const double* dz, double t, double* g_out) {
   if (host_solve_)
     hip_check(hipMemcpyAsync(lv.h_g.p, g_out, (size_t)lv.plan.N * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
               "D2H g");
-  sync_collect("sync f1");
+  if (pre && st && !host_solve_) {
+    ensure_chol(lv);
+    if (!ev_f1_) hip_check(hipEventCreateWithFlags(&ev_f1_, hipEventDisableTiming), "event");
+    hip_check(hipEventRecord(ev_f1_, ctx_.stream), "record f1");
+    enqueue_f2_assemble(lv, dz, *st);
+    *pre = dz;
+    hip_check(hipEventSynchronize(ev_f1_), "sync f1 event");      // timer events are collected at the next full sync
+  } else {
+    sync_collect("sync f1");
+  }
   return std::sqrt(h_scal_.p[2]);
 }
 
@@ -558,17 +582,11 @@ void Amg::enqueue_trial(Level& lv, Trial& T, double step, int slot) {
   T.step = step;      // the caller copies scal_[3..7] (inc + both trials) back in one transfer
 }
 
-bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, double* inc, Trial* spec) {
+bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, double* inc, Trial* spec,
+                       const double* pre_assembled) {
   const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
   ensure_chol(lv);
-  timer_.begin(ctx_.stream, KC_F2, (double)n_ * (P_.K + 1 + P_.nY()) * 8);
-  launch_barrier_f2(ctx_.stream, n_, P_, dz, w_.p, Y_.p);
-  timer_.end(ctx_.stream);
-  timer_.begin(ctx_.stream, KC_ASSEMBLE, csr_bytes(lv.T.view, false));
-  launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
-  timer_.end(ctx_.stream);
-  ctx_.allreduce_sum(lv.avals.p, nnzA);      // sharded: every rank then factors the same replicated matrix
-  st.n_f2++;
+  if (pre_assembled != dz) enqueue_f2_assemble(lv, dz, st);      // else: done behind the gradient of this point
   st.n_factor++;
   // event pairs cost ~14 % of a solve when every launch is bracketed: time every 8th Newton step only
   timer_.sample((st.n_factor % 8) == 1);
@@ -687,12 +705,15 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
     X.valid = true;
     return X.y;
   };
+  const double* pre = nullptr;      // Dz buffer whose Hessian values were assembled behind its gradient
+  const bool speculate = !host_solve_;
   while (res.k < maxit && !res.converged) {
     res.k++;
     double inc = 0;
     T[0].valid = T[1].valid = false;
-    const bool speculate = !host_solve_;
-    if (!dev_f2_solve(lv, Dz_.p, t, st, &inc, speculate ? T : nullptr)) {
+    const double* have = pre;      // Hessian values already assembled for this Dz buffer?
+    pre = nullptr;
+    if (!dev_f2_solve(lv, Dz_.p, t, st, &inc, speculate ? T : nullptr, have)) {
       if (verbose > 1) fprintf(stderr, "    [mgb] level %d k=%d: Hessian not numerically SPD (pivot flag %d)\n", l, res.k, h_flag_.p[0]);
       break;
     }
@@ -720,7 +741,7 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
           yA = yB;
           step *= kBeta;
         }
-        const double gn = dev_f1(lv, T[0].dz, t, lv.g_trial.p);
+        const double gn = dev_f1(lv, T[0].dz, t, lv.g_trial.p, &st, speculate ? &pre : nullptr);
         st.n_f1++;
         if (std::isfinite(gn)) {
           ynext = yA;

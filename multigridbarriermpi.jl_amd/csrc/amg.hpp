@@ -253,7 +253,16 @@ class Amg {
   int fused_trial_rows_ = 64 * 2048;      // trial_f0_kernel on launch-bound meshes (env MGB_FUSED_TRIAL_ROWS)
   void enqueue_f0(Level& lv, const double* s_dev, double alpha, const double* nstep, double* s_out, double* dz,
                   const double* phi_ref, double* phi_out, double* out2);      // no host sync
-  double dev_f1(Level& lv, const double* dz, double t, double* g_out);   // gradient from the Dz of the point; returns |g|
+  // gradient from the Dz of the point; returns |g|.  pre != nullptr: also assembles the point's Hessian values behind it
+  double dev_f1(Level& lv, const double* dz, double t, double* g_out, SolveStats* st = nullptr, const double** pre = nullptr);
+  void enqueue_f2_assemble(Level& lv, const double* dz, SolveStats& st);
+  struct EventHolder {      // owns the event the host waits on for |g|
+    hipEvent_t e = nullptr;
+    ~EventHolder() {
+      if (e) (void)hipEventDestroy(e);
+    }
+  } ev_f1_holder_;
+  hipEvent_t& ev_f1_ = ev_f1_holder_.e;
   // one line-search trial point s - step * nstep with its scratch buffers and (cached) objective value
   struct Trial {
     double* s = nullptr;
@@ -265,7 +274,8 @@ class Amg {
   // Hessian at s, nstep = H \ g.  With `spec` (device solver only) the first two line-search trials (steps 1 and
   // 1/2, the two points every line search evaluates first) are enqueued behind the solve and read back with the
   // same host synchronisation: two fewer round trips per Newton step.
-  bool dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, double* inc, Trial* spec = nullptr);
+  bool dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, double* inc, Trial* spec = nullptr,
+                    const double* pre_assembled = nullptr);
   void enqueue_trial(Level& lv, Trial& T, double step, int slot);
   NewtonResult newton(int l, double t, bool finest, double lam_tol, int maxit, SolveStats& st, int verbose);
   bool amgb_step(double t, double lam_tol, int max_newton, std::vector<long long>& its, SolveStats& st, int verbose);
