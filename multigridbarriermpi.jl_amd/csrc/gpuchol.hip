@@ -59,9 +59,14 @@ __device__ inline double readlane_f64(double v, int lane) {
 // (zero above the diagonal).
 // Called by every thread of the workgroup (contains a barrier); D must be visible (barrier) before the call.
 // Lo: 32 x LP LDS scratch, distinct from D.
+// LDS pointers are passed in their own address space: through a generic `double*` every access re-derives the LDS
+// address with a null check (v_cmp + v_cndmask per read), which costs issue slots on the single-wave critical path
+using lds_f64 = __attribute__((address_space(3))) double*;
+using lds_cf64 = const __attribute__((address_space(3))) double*;
+
 // the 16 rounds of the in-register factorisation: straight-line code, or (BRK) with an exit test per round
 template <bool BRK>
-__device__ inline void factor_rounds(double (&a)[PB / 2], double* col, int i, int h, bool& bad, int kw) {
+__device__ inline void factor_rounds(double (&a)[PB / 2], lds_f64 col, int i, int h, bool& bad, int kw) {
 #pragma unroll
   for (int kk = 0; kk < PB / 2; ++kk) {
     const int k = 2 * kk, hk = kk & 1, mk = kk >> 1;
@@ -117,7 +122,7 @@ __device__ inline void factor_rounds(double (&a)[PB / 2], double* col, int i, in
 __device__ inline constexpr int lo_packed(int r, int c) { return r * (r + 1) / 2 + c; }
 
 template <bool EXIT = false, bool PACKED = false>
-__device__ void factor_diag_block(const double* D, int kw, double* Lo, double* lp, int* fail, long long* prof) {
+__device__ __forceinline__ void factor_diag_block(const double* D, int kw, double* Lo, double* lp, int* fail, long long* prof) {
   const int tid = threadIdx.x;
   if (tid < 64) {
     const int i = tid & 31, h = tid >> 5;
@@ -130,7 +135,7 @@ __device__ void factor_diag_block(const double* D, int kw, double* Lo, double* l
       a[q] = v;
     }
     bool bad = false;
-    double* col = Lo;      // the broadcast line aliases the output block, which is only written after the loop
+    lds_f64 col = (lds_f64)Lo;      // the broadcast line aliases the output block, which is only written after the loop
     if (EXIT) factor_rounds<true>(a, col, i, h, bad, kw);
     else factor_rounds<false>(a, col, i, h, bad, PB);
     STAMP(6);
