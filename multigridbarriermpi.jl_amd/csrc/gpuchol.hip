@@ -362,13 +362,13 @@ __device__ inline int tile_pos(int r) { return 4 * (r & 15) + (r >> 4); }   // L
 __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void front_step_kernel(const StepTile* __restrict__ tiles, int p, int npiv, double* fronts,
                                                          const double* __restrict__ linv_ro, double* linv, int* fail,
                                                          long long* prof) {
-  // panel rows of the tile, transposed: AT[q * 64 + tile_pos(r)] = (row r, panel column q).  The slot
-  // permutation puts the four rows tx, tx+16, tx+32, tx+48 of a thread's micro-tile next to each other, so
-  // the rank-32 update reads them with one 32-byte LDS access while the global accesses stay coalesced.
-  __shared__ __attribute__((aligned(32))) double sh[2 * PB * TS + PB * PB];
+  // panel rows of the tile, transposed: AT[q * TP + r] = (row r, panel column q): unit stride over the rows for the
+  // staging, the substitution (lane = row) and the MFMA operand reads (16 rows x 4 panel columns per read).
+  constexpr int TP = TS + 8;      // row stride of the staged panel blocks: the four k-groups of an MFMA operand read land on disjoint banks
+  __shared__ __attribute__((aligned(32))) double sh[2 * PB * TP + PB * PB];
   double* ATI = sh;
-  double* ATJ = sh + PB * TS;
-  double* Lc = sh + 2 * PB * TS;      // column-major pivot block: Lc[32 j + m] = L[m][j]
+  double* ATJ = sh + PB * TP;
+  double* Lc = sh + 2 * PB * TP;      // column-major pivot block: Lc[32 j + m] = L[m][j]
   STAMP(0);
   const StepTile t = tiles[blockIdx.x];
   if ((int)blockIdx.x < npiv) {      // workgroup-uniform: the dedicated pivot workgroup of one front
@@ -380,12 +380,12 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   const int r0 = k1 + TS * t.ti, c0 = k1 + TS * t.tj;
   const bool diag = (t.ti == t.tj);
   const int tid = threadIdx.x;
-  const int tx = tid & 15, ty = tid >> 4;
   for (int idx = tid; idx < PB * PB; idx += TB) Lc[idx] = linv_ro[t.loff + PB * PB + idx];
+  // panel rows of the tile, transposed and padded: AT[q * TP + r] = (row r, panel column q)
   for (int idx = tid; idx < TS * PB; idx += TB) {
     const int r = idx % TS, q = idx / TS;
-    ATI[q * TS + tile_pos(r)] = (q < kw && r0 + r <= nf) ? F[(long long)ld * (k0 + q) + r0 + r] : 0.0;
-    if (!diag) ATJ[q * TS + tile_pos(r)] = (q < kw && c0 + r <= nf) ? F[(long long)ld * (k0 + q) + c0 + r] : 0.0;
+    ATI[q * TP + r] = (q < kw && r0 + r <= nf) ? F[(long long)ld * (k0 + q) + r0 + r] : 0.0;
+    if (!diag) ATJ[q * TP + r] = (q < kw && c0 + r <= nf) ? F[(long long)ld * (k0 + q) + c0 + r] : 0.0;
   }
   __syncthreads();
   STAMP(1);
@@ -393,13 +393,13 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     // thread = one row of I (wave 0) or J (wave 1), in registers: X L11' = A by right-looking substitution;
     // column j of L11 is contiguous in the column-major copy, read two entries per (broadcast) LDS access
     const int r = tid & (TS - 1);
-    double* A = ((tid < TS) ? ATI : ATJ) + tile_pos(r);
+    double* A = ((tid < TS) ? ATI : ATJ) + r;
     double f[PB];
 #pragma unroll
-    for (int m = 0; m < PB; ++m) f[m] = A[m * TS];
+    for (int m = 0; m < PB; ++m) f[m] = A[m * TP];
     trsm_row(f, Lc);
 #pragma unroll
-    for (int m = 0; m < PB; ++m) A[m * TS] = f[m];
+    for (int m = 0; m < PB; ++m) A[m * TP] = f[m];
     if (t.tj == 0 && tid < TS && r0 + r <= nf) {         // finished rows of L go to the mirrored (upper) half
       double* Lrow = F + (long long)ld * (r0 + r) + k0;
 #pragma unroll
@@ -409,41 +409,42 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   }
   __syncthreads();
   STAMP(2);
-  // the C micro-tile (4x4 per thread) is requested here so that its latency hides behind the rank-32 update;
-  // the 32x32 corner that becomes the next pivot block belongs to the pivot workgroup
+  // Rank-32 update C[I, J] -= L_I L_J' on the matrix cores: v_mfma_f64_16x16x4_f64, D[m][n] += A[m][k] B[k][n] with
+  // m = tile column (L_J), n = tile row (L_I), so that the lanes of a result register run along the rows of the
+  // front (unit stride in HBM).  Wave w owns tile rows 16 w .. 16 w + 15 and all four 16-column blocks: lane
+  // (li = lane & 15, lk = lane >> 4) holds C[16 w + li][16 bj + lk + 4 reg] in acc[bj][reg]; per k-step of 4 panel
+  // columns it reads ONE L_I entry and four L_J entries from LDS (a quarter of the operand traffic of the 4x4
+  // register micro-tiles).  The 32x32 corner that becomes the next pivot block belongs to the pivot workgroup.
   const int kc = (t.ti == 0 && t.tj == 0) ? min(t.ns, k1 + PB) : 0;      // rows/columns < kc: the next pivot block
+  const int lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
+  const int i = r0 + 16 * w + li;
+  typedef double v4f64 __attribute__((ext_vector_type(4)));
   double c[4][4];
 #pragma unroll
-  for (int bq = 0; bq < 4; ++bq)
+  for (int bj = 0; bj < 4; ++bj)
 #pragma unroll
-    for (int aq = 0; aq < 4; ++aq) {
-      const int i = r0 + tx + 16 * aq, j = c0 + ty + 16 * bq;
-      c[aq][bq] = (i <= nf && j < nf && i >= j && !(i < kc && j < kc)) ? F[(long long)ld * j + i] : 0.0;
+    for (int reg = 0; reg < 4; ++reg) {
+      const int j = c0 + 16 * bj + lk + 4 * reg;
+      c[bj][reg] = (i <= nf && j < nf && i >= j && !(i < kc && j < kc)) ? F[(long long)ld * j + i] : 0.0;
     }
-  const double* LI = ATI + 4 * tx;
-  const double* LJ = (diag ? ATI : ATJ) + 4 * ty;
-  double acc[4][4];
+  const double* LI = ATI + 16 * w + li + lk * TP;
+  const double* LJ = (diag ? ATI : ATJ) + li + lk * TP;
+  v4f64 acc[4];
 #pragma unroll
-  for (int aq = 0; aq < 4; ++aq)
+  for (int bj = 0; bj < 4; ++bj) acc[bj] = v4f64{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = 0.0;
-#pragma unroll 8
-  for (int q = 0; q < PB; ++q) {
-    const double4 xv = *reinterpret_cast<const double4*>(LI + q * TS);
-    const double4 yv = *reinterpret_cast<const double4*>(LJ + q * TS);
-    const double x[4] = {xv.x, xv.y, xv.z, xv.w}, y[4] = {yv.x, yv.y, yv.z, yv.w};
+  for (int ks = 0; ks < PB / 4; ++ks) {
+    const double bv = LI[4 * ks * TP];
 #pragma unroll
-    for (int aq = 0; aq < 4; ++aq)
-#pragma unroll
-      for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = fma(x[aq], y[bq], acc[aq][bq]);
+    for (int bj = 0; bj < 4; ++bj)
+      acc[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(LJ[4 * ks * TP + 16 * bj], bv, acc[bj], 0, 0, 0);
   }
 #pragma unroll
-  for (int bq = 0; bq < 4; ++bq)
+  for (int bj = 0; bj < 4; ++bj)
 #pragma unroll
-    for (int aq = 0; aq < 4; ++aq) {
-      const int i = r0 + tx + 16 * aq, j = c0 + ty + 16 * bq;
-      c[aq][bq] -= acc[aq][bq];
-      if (i <= nf && j < nf && i >= j && !(i < kc && j < kc)) F[(long long)ld * j + i] = c[aq][bq];
+    for (int reg = 0; reg < 4; ++reg) {
+      const int j = c0 + 16 * bj + lk + 4 * reg;
+      if (i <= nf && j < nf && i >= j && !(i < kc && j < kc)) F[(long long)ld * j + i] = c[bj][reg] - acc[bj][reg];
     }
   STAMP(3);
   STAMP(7);
