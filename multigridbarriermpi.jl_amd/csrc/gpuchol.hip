@@ -429,12 +429,12 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     }
   const double* LI = ATI + 16 * w + li + lk * TP;
   const double* LJ = (diag ? ATI : ATJ) + li + lk * TP;
-  v4f64 acc[4];
+  v4f64 acc[4];      // starts as C; the negated L_I operand makes the matrix core return C - L_I L_J'
 #pragma unroll
-  for (int bj = 0; bj < 4; ++bj) acc[bj] = v4f64{0.0, 0.0, 0.0, 0.0};
+  for (int bj = 0; bj < 4; ++bj) acc[bj] = v4f64{c[bj][0], c[bj][1], c[bj][2], c[bj][3]};
 #pragma unroll
   for (int ks = 0; ks < PB / 4; ++ks) {
-    const double bv = LI[4 * ks * TP];
+    const double bv = -LI[4 * ks * TP];
 #pragma unroll
     for (int bj = 0; bj < 4; ++bj)
       acc[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(LJ[4 * ks * TP + 16 * bj], bv, acc[bj], 0, 0, 0);
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int j = c0 + 16 * bj + lk + 4 * reg;
-      if (i <= nf && j < nf && i >= j && !(i < kc && j < kc)) F[(long long)ld * j + i] = c[bj][reg] - acc[bj][reg];
+      if (i <= nf && j < nf && i >= j && !(i < kc && j < kc)) F[(long long)ld * j + i] = acc[bj][reg];
     }
   STAMP(3);
   STAMP(7);
@@ -460,16 +460,17 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 // NARROW: launches whose fronts have at most 8 pivots skip the identity padding in the factor, the substitution,
 // the update and the gather of the panel columns.
 template <bool NARROW>
-__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void front_single_kernel(
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void front_single_kernel(
     const SingleTile* __restrict__ tiles, const int* __restrict__ pinv,
     const int* __restrict__ asm_src, const int* __restrict__ asm_pos, const double* __restrict__ vals,
     const int* __restrict__ perm, const double* __restrict__ b, const double* __restrict__ fronts_ro, double* fronts,
     double* linv, int* fail, long long* prof) {
-  __shared__ __attribute__((aligned(32))) double sh[2 * PB * TS + PB * PB + 2 * PB * LP];
+  constexpr int TP = TS + 8;      // row stride of the staged panel blocks (as in front_step)
+  __shared__ __attribute__((aligned(32))) double sh[2 * PB * TP + PB * PB + 2 * PB * LP];
   __shared__ int rowI[2][TS], rowJ[2][TS], piv[2][PB];
   double* ATI = sh;
-  double* ATJ = sh + PB * TS;
-  double* Lc = sh + 2 * PB * TS;
+  double* ATJ = sh + PB * TP;
+  double* Lc = sh + 2 * PB * TP;
   double* D = Lc + PB * PB;
   double* Lo = D + PB * LP;
   STAMP(0);
@@ -478,7 +479,8 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   double* F = fronts + t.off;
   const int r0 = k1 + TS * t.ti, c0 = k1 + TS * t.tj;
   const bool diag = (t.ti == t.tj);
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;      // C layout of the MFMA update (front_step)
   const bool has[2] = {t.cld[0] > 0, t.cld[1] > 0};
   const int cld[2] = {t.cld[0], t.cld[1]};
   const int* __restrict__ inv0 = pinv + (has[0] ? t.iofs : 0);
@@ -503,12 +505,12 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   };
   double c[4][4];
 #pragma unroll
-  for (int bq = 0; bq < 4; ++bq)
+  for (int bj = 0; bj < 4; ++bj)
 #pragma unroll
-    for (int aq = 0; aq < 4; ++aq) {
-      const int r = tx + 16 * aq, cc = ty + 16 * bq, i = r0 + r, j = c0 + cc;
+    for (int reg = 0; reg < 4; ++reg) {
+      const int r = 16 * w + li, cc = 16 * bj + lk + 4 * reg, i = r0 + r, j = c0 + cc;
       const bool in = (i <= nf && j < nf && i >= j);
-      c[aq][bq] = in ? child(rowI[0][r], rowJ[0][cc], rowI[1][r], rowJ[1][cc]) : 0.0;
+      c[bj][reg] = in ? child(rowI[0][r], rowJ[0][cc], rowI[1][r], rowJ[1][cc]) : 0.0;
     }
   {
     const int r = tid % TS, qg = tid / TS;      // 64 rows x 4 groups of 8 pivot columns
@@ -524,8 +526,8 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      ATI[(qg * 8 + u) * TS + tile_pos(r)] = vi[u];
-      if (!diag) ATJ[(qg * 8 + u) * TS + tile_pos(r)] = vj[u];
+      ATI[(qg * 8 + u) * TP + r] = vi[u];
+      if (!diag) ATJ[(qg * 8 + u) * TP + r] = vj[u];
     }
     const int i = tid % PB, jg = tid / PB;      // pivot block: 32 rows x 8 groups of 4 columns
 #pragma unroll
@@ -554,13 +556,13 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       const int col = pos[u] / ld, row = pos[u] - col * ld;
       if (row < ns) D[row * LP + col] += v[u];
       else {
-        if (row >= r0 && row < r0 + TS) ATI[col * TS + tile_pos(row - r0)] += v[u];
-        if (!diag && row >= c0 && row < c0 + TS) ATJ[col * TS + tile_pos(row - c0)] += v[u];
+        if (row >= r0 && row < r0 + TS) ATI[col * TP + row - r0] += v[u];
+        if (!diag && row >= c0 && row < c0 + TS) ATJ[col * TP + row - c0] += v[u];
       }
     }
   }
   if (nf >= r0 && nf < r0 + TS)
-    for (int q = tid; q < ns; q += TB) ATI[q * TS + tile_pos(nf - r0)] += b[perm[t.first + q]];
+    for (int q = tid; q < ns; q += TB) ATI[q * TP + nf - r0] += b[perm[t.first + q]];
   __syncthreads();
   factor_diag_block<NARROW>(D, kw, Lo, (t.ti == 0 && t.tj == 0) ? linv + t.loff : nullptr, fail, nullptr);
   for (int idx = tid; idx < PB * PB; idx += TB) Lc[idx] = Lo[(idx % PB) * LP + idx / PB];     // Lc[32 j + m] = L[m][j]
@@ -568,13 +570,13 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   STAMP(2);
   if (tid < 2 * TS && (tid < TS || !diag)) {
     const int r = tid & (TS - 1);
-    double* A = ((tid < TS) ? ATI : ATJ) + tile_pos(r);
+    double* A = ((tid < TS) ? ATI : ATJ) + r;
     double f[PB];
 #pragma unroll
-    for (int m = 0; m < PB; ++m) f[m] = A[m * TS];
+    for (int m = 0; m < PB; ++m) f[m] = A[m * TP];
     trsm_row<NARROW>(f, Lc, kw);
 #pragma unroll
-    for (int m = 0; m < PB; ++m) A[m * TS] = f[m];
+    for (int m = 0; m < PB; ++m) A[m * TP] = f[m];
     if (t.tj == 0 && tid < TS && r0 + r <= nf) {
       double* Lrow = F + (long long)ld * (r0 + r);
 #pragma unroll
@@ -584,29 +586,26 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   }
   __syncthreads();
   STAMP(3);
-  const double* LI = ATI + 4 * tx;
-  const double* LJ = (diag ? ATI : ATJ) + 4 * ty;
-  double acc[4][4];
+  // rank-32 (rank-8 when NARROW) update on the matrix cores, operand and result layout as in front_step
+  typedef double v4f64 __attribute__((ext_vector_type(4)));
+  const double* LI = ATI + 16 * w + li + lk * TP;
+  const double* LJ = (diag ? ATI : ATJ) + li + lk * TP;
+  v4f64 acc[4];      // starts as C; the negated L_I operand makes the matrix core return C - L_I L_J'
 #pragma unroll
-  for (int aq = 0; aq < 4; ++aq)
+  for (int bj = 0; bj < 4; ++bj) acc[bj] = v4f64{c[bj][0], c[bj][1], c[bj][2], c[bj][3]};
 #pragma unroll
-    for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = 0.0;
-#pragma unroll 8
-  for (int q = 0; q < (NARROW ? 8 : PB); ++q) {
-    const double4 xv = *reinterpret_cast<const double4*>(LI + q * TS);
-    const double4 yv = *reinterpret_cast<const double4*>(LJ + q * TS);
-    const double x[4] = {xv.x, xv.y, xv.z, xv.w}, y[4] = {yv.x, yv.y, yv.z, yv.w};
+  for (int ks = 0; ks < (NARROW ? 2 : PB / 4); ++ks) {
+    const double bv = -LI[4 * ks * TP];
 #pragma unroll
-    for (int aq = 0; aq < 4; ++aq)
-#pragma unroll
-      for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = fma(x[aq], y[bq], acc[aq][bq]);
+    for (int bj = 0; bj < 4; ++bj)
+      acc[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(LJ[4 * ks * TP + 16 * bj], bv, acc[bj], 0, 0, 0);
   }
 #pragma unroll
-  for (int bq = 0; bq < 4; ++bq)
+  for (int bj = 0; bj < 4; ++bj)
 #pragma unroll
-    for (int aq = 0; aq < 4; ++aq) {
-      const int i = r0 + tx + 16 * aq, j = c0 + ty + 16 * bq;
-      if (i <= nf && j < nf && i >= j) F[(long long)ld * j + i] = c[aq][bq] - acc[aq][bq];
+    for (int reg = 0; reg < 4; ++reg) {
+      const int i = r0 + 16 * w + li, j = c0 + 16 * bj + lk + 4 * reg;
+      if (i <= nf && j < nf && i >= j) F[(long long)ld * j + i] = acc[bj][reg];
     }
   STAMP(7);
 }
