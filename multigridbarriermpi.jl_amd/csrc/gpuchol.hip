@@ -357,7 +357,6 @@ __device__ inline void pivot_path(const StepTile& t, int p, double* sh, double* 
   STAMP(7);
 }
 
-__device__ inline int tile_pos(int r) { return 4 * (r & 15) + (r >> 4); }   // LDS slot of tile row r (see below)
 
 __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void front_step_kernel(const StepTile* __restrict__ tiles, int p, int npiv, double* fronts,
                                                          const double* __restrict__ linv_ro, double* linv, int* fail,
@@ -622,12 +621,13 @@ __global__ __launch_bounds__(TB, 4) void front_leaf_kernel(
   extern __shared__ __attribute__((aligned(32))) double sm[];
   STAMP(0);
   const GNode nd = nodes[list[blockIdx.x]];
-  const int nf = nd.nf, ld = nf + 1, ns = nd.ns, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  __shared__ __attribute__((aligned(32))) double fixed[TS * PB + PB * (PB + 1) / 2];      // AT (also D) | Lo (packed)
+  const int nf = nd.nf, ld = nf + 1, ns = nd.ns, tid = threadIdx.x;
+  constexpr int TP = TS + 8;      // row stride of the staged panel rows (as in front_step)
+  __shared__ __attribute__((aligned(32))) double fixed[TP * PB + PB * (PB + 1) / 2];      // AT (also D) | Lo (packed)
   double* Fs = sm;                               // the front, (nf+1)-leading-dimension layout as in HBM
   double* AT = fixed;                            // staging tile of the panel rows (front_step layout), 32 x 64
   double* D = fixed;                             // the pivot block is dead once factored: same storage
-  double* Lo = fixed + TS * PB;                  // row-major packed factor, reciprocal diagonal
+  double* Lo = fixed + TP * PB;                  // row-major packed factor, reciprocal diagonal
   // packed lower-triangular storage of the front (column j holds rows j..nf): half the LDS of the square layout,
   // which (with the packed pivot-block factor) is what lets four workgroups share a CU
   auto P = [ld](int i, int j) { return j * ld - (j * (j - 1)) / 2 + (i - j); };
@@ -655,17 +655,17 @@ __global__ __launch_bounds__(TB, 4) void front_leaf_kernel(
     // substitution and the rank-32 update are literally the code of front_step (constant LDS strides)
     for (int idx = tid; idx < TS * PB; idx += TB) {
       const int r = idx % TS, q = idx / TS;
-      AT[q * TS + tile_pos(r)] = (q < kw && k1 + r <= nf) ? Fs[P(k1 + r, k0 + q)] : 0.0;
+      AT[q * TP + r] = (q < kw && k1 + r <= nf) ? Fs[P(k1 + r, k0 + q)] : 0.0;
     }
     __syncthreads();
     if (tid < TS) {
-      double* A = AT + tile_pos(tid);
+      double* A = AT + tid;
       double f[PB];
 #pragma unroll
-      for (int m = 0; m < PB; ++m) f[m] = A[m * TS];
+      for (int m = 0; m < PB; ++m) f[m] = A[m * TP];
       trsm_row_lo(f, Lo, kw);
 #pragma unroll
-      for (int m = 0; m < PB; ++m) A[m * TS] = f[m];
+      for (int m = 0; m < PB; ++m) A[m * TP] = f[m];
       if (k1 + tid <= nf) {
         double* Lrow = F + (long long)ld * (k1 + tid) + k0;   // mirrored L for the backward sweep
 #pragma unroll
@@ -674,29 +674,27 @@ __global__ __launch_bounds__(TB, 4) void front_leaf_kernel(
       }
     }
     __syncthreads();
-    const double* LI = AT + 4 * tx;
-    const double* LJ = AT + 4 * ty;
-    double acc[4][4];
+    // rank-kw update of the 64x64 trailing tile on the matrix cores (operand / result layout of front_step)
+    typedef double v4f64 __attribute__((ext_vector_type(4)));
+    const int lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const double* LI = AT + 16 * w + li + lk * TP;
+    const double* LJ = AT + li + lk * TP;
+    v4f64 acc[4];
 #pragma unroll
-    for (int aq = 0; aq < 4; ++aq)
+    for (int bj = 0; bj < 4; ++bj) acc[bj] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int ks = 0; ks < (kw + 3) / 4; ++ks) {      // staged rows >= kw are zero
+      const double bv = LI[4 * ks * TP];
 #pragma unroll
-      for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = 0.0;
-#pragma unroll 8
-    for (int q = 0; q < ((kw + 7) & ~7); ++q) {
-      const double4 xv = *reinterpret_cast<const double4*>(LI + q * TS);
-      const double4 yv = *reinterpret_cast<const double4*>(LJ + q * TS);
-      const double x[4] = {xv.x, xv.y, xv.z, xv.w}, y[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-      for (int aq = 0; aq < 4; ++aq)
-#pragma unroll
-        for (int bq = 0; bq < 4; ++bq) acc[aq][bq] = fma(x[aq], y[bq], acc[aq][bq]);
+      for (int bj = 0; bj < 4; ++bj)
+        acc[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(LJ[4 * ks * TP + 16 * bj], bv, acc[bj], 0, 0, 0);
     }
 #pragma unroll
-    for (int bq = 0; bq < 4; ++bq)
+    for (int bj = 0; bj < 4; ++bj)
 #pragma unroll
-      for (int aq = 0; aq < 4; ++aq) {
-        const int i = k1 + tx + 16 * aq, j = k1 + ty + 16 * bq;
-        if (i <= nf && j < nf && i >= j) Fs[P(i, j)] -= acc[aq][bq];
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = k1 + 16 * w + li, j = k1 + 16 * bj + lk + 4 * reg;
+        if (i <= nf && j < nf && i >= j) Fs[P(i, j)] -= acc[bj][reg];
       }
     __syncthreads();
   };
