@@ -2,11 +2,13 @@
 //
 // Roofline: at the benchmark sizes this solver is bound by the LENGTH of its dependent launch chain (one
 // launch per 32 pivot columns along the tallest root-to-leaf path of the elimination tree), not by HBM or
-// the fp64 pipes: ~1.5 GFLOP and ~230 MB of fronts per fine-level factorisation at fem2d L=7, all of it
+// the fp64 pipes: 0.35 GFLOP and 106 MB of fronts per fine-level factorisation at fem2d L=7, all of it
 // L2 / Infinity-Cache resident.  The design therefore minimises launches and dependent global-memory
 // round trips per launch (descriptor -> operands -> results), and spends redundant flops freely (every
-// tile re-derives its two 64x32 panel blocks instead of waiting for a separate TRSM launch).  No MFMA:
-// fp64 matrix and vector peaks are equal on MI355X and the tiles are ragged / triangular.
+// tile re-derives its two 64x32 panel blocks instead of waiting for a separate TRSM launch).  The rank-32
+// trailing updates run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): same peak as the vector unit on
+// MI355X, but one instruction per 1 024 multiply-adds and a quarter of the LDS operand traffic, which is
+// what counts on larger meshes (fem2d L >= 8, fem3d) where the launches are throughput-bound.
 #include "gpuchol.hpp"
 
 #include "amg.hpp"
