@@ -319,12 +319,20 @@ __device__ inline void pivot_path(const StepTile& t, int p, double* sh, double* 
   double* F = fronts + t.off;
   const int tid = threadIdx.x;
   for (int idx = tid; idx < PB * PB; idx += TB) Lc[idx] = linv_ro[t.loff + PB * PB + idx];
-  const int ci = tid & 31, cj = tid >> 5;       // corner entry (ci, cj + 8 b), b = 0..3
-  double c[4];
+  // the corner as three 16x16 blocks of the lower triangle, one per wave (wave 3 idles), in the result layout of
+  // v_mfma_f64_16x16x4_f64 with m = corner column, n = corner row: lane (li, lk) holds (row 16 bi + li, column
+  // 16 bj + lk + 4 reg), so the loads run along the rows of the front
+  typedef double v4f64 __attribute__((ext_vector_type(4)));
+  const int lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
+  const int bi = (w + 1) >> 1, bj = w >> 1;      // waves 0, 1, 2 -> blocks (0,0), (1,0), (1,1)
+  const int ci = 16 * bi + li;
+  v4f64 acc = v4f64{0.0, 0.0, 0.0, 0.0};
+  if (w < 3) {
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int j = cj + 8 * b;
-    c[b] = (j <= ci && ci < kw2) ? F[(long long)ld * (k1 + j) + k1 + ci] : 0.0;
+    for (int reg = 0; reg < 4; ++reg) {
+      const int j = 16 * bj + lk + 4 * reg;
+      acc[reg] = (j <= ci && ci < kw2) ? F[(long long)ld * (k1 + j) + k1 + ci] : 0.0;
+    }
   }
   double f[PB];
   if (tid < PB) {
@@ -340,16 +348,13 @@ __device__ inline void pivot_path(const StepTile& t, int p, double* sh, double* 
   }
   __syncthreads();
   STAMP(2);
+  if (w < 3) {      // wave-uniform: C - P_i P_j' on the matrix cores (negated row operand, C as accumulator input)
+    const double* PI = P + ci * LP + lk;
+    const double* PJ = P + (16 * bj + li) * LP + lk;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int j = cj + 8 * b;
-    double a0 = 0.0, a1 = 0.0;
+    for (int ks = 0; ks < PB / 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(PJ[4 * ks], -PI[4 * ks], acc, 0, 0, 0);
 #pragma unroll
-    for (int q = 0; q < PB; q += 2) {
-      a0 = fma(P[ci * LP + q], P[j * LP + q], a0);
-      a1 = fma(P[ci * LP + q + 1], P[j * LP + q + 1], a1);
-    }
-    D[ci * LP + j] = c[b] - (a0 + a1);
+    for (int reg = 0; reg < 4; ++reg) D[ci * LP + 16 * bj + lk + 4 * reg] = acc[reg];      // entries right of the diagonal: don't care
   }
   STAMP(3);
   __syncthreads();
