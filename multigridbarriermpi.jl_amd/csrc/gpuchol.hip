@@ -293,14 +293,24 @@ __device__ inline void trsm_row_lo(double (&f)[PB], const double* Lo, int kw) {
 #pragma unroll
   for (int j = 0; j < PB; ++j) {
     if ((j & 7) == 0 && j >= kw) break;      // identity padding
-    double lc[PB];
+    // the column in two register windows of 16 (the kernel runs at 128 VGPRs, f alone takes 64)
+    constexpr int H = PB / 2;
+    const int m0 = j, m1 = (j < H) ? H : PB;
+    double lc[H];
 #pragma unroll
-    for (int m = j; m < PB; ++m) lc[m] = Lo[lo_packed(m, j)];
+    for (int m = m0; m < m1; ++m) lc[m - m0] = Lo[lo_packed(m, j)];
     asm volatile("" ::: "memory");
-    const double fj = f[j] * lc[j];
+    const double fj = f[j] * lc[0];
     f[j] = fj;
 #pragma unroll
-    for (int m = j + 1; m < PB; ++m) f[m] = fma(-fj, lc[m], f[m]);
+    for (int m = m0 + 1; m < m1; ++m) f[m] = fma(-fj, lc[m - m0], f[m]);
+    if (j < H) {
+#pragma unroll
+      for (int m = H; m < PB; ++m) lc[m - H] = Lo[lo_packed(m, j)];
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int m = H; m < PB; ++m) f[m] = fma(-fj, lc[m - H], f[m]);
+    }
   }
 }
 
