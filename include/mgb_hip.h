@@ -85,10 +85,24 @@ int mgb_vec_download(mgb_vec v, double* host);                /* Vector(x) gathe
 int mgb_csr_create(mgb_ctx ctx, int rows, int cols, const int32_t* rowptr, const int32_t* colidx,
                    const double* vals, mgb_csr* out);         /* HPCSparseMatrix(S, backend) src:271 */
 int mgb_csr_free(mgb_csr A);
+int mgb_csr_dims(mgb_csr A, int* rows, int* cols, int* nnz);
+int mgb_csr_get(mgb_csr A, int32_t* rowptr, int32_t* colidx, double* vals);   /* SparseMatrixCSC(x) gather, src:371,381 */
+/* setup-time sparse algebra MultiGridBarrier applies to M; structural patterns (entries that cancel to 0 are
+ * kept: the reference hit a cancellation-dependent sparsity bug, test/test_matrix_addition.jl:21-24).  The symbolic
+ * work runs on the host copy of the operands (setup, not the Newton path); the result is device resident. */
+int mgb_csr_spgemm(mgb_csr A, mgb_csr B, mgb_csr* out);        /* M*M, M'*M  test/test_basic_ops.jl:39,55; test_nonsquare.jl:83 */
+int mgb_csr_transpose(mgb_csr A, mgb_csr* out);                /* materialize_transpose, test/test_transpose_only.jl:38,58 */
+int mgb_csr_add(mgb_csr A, double alpha, mgb_csr B, mgb_csr* out);  /* M + alpha*M  test/test_matrix_addition.jl:48-63; scalar*M tools/profile_ops.jl:117 */
+int mgb_csr_hcat(int count, const mgb_csr* mats, mgb_csr* out);     /* hcat(M...)  test/test_d0_construction.jl:92-100 */
+int mgb_csr_blockdiag(int count, const mgb_csr* mats, mgb_csr* out); /* amgb_blockdiag src:150; test/test_helpers.jl:117-121 */
 int mgb_diag(mgb_ctx ctx, mgb_vec z, int m, int n, mgb_csr* out);  /* amgb_diag: spdiagm(m,n,0=>z) src:137-147 */
 int mgb_spmv(mgb_csr A, mgb_vec x, mgb_vec y);                /* y = A*x   (HPCSparseMatrix * HPCVector, test_nonsquare.jl:43) */
 int mgb_spmv_add(mgb_csr A, mgb_vec x, mgb_vec y0, mgb_vec y); /* y = y0 + A*x */
 int mgb_dot(mgb_vec x, mgb_vec y, double* out);               /* dot(w,y) tools/profile_scaling.jl:102 */
+int mgb_norm(mgb_vec x, double* out);                         /* norm(x) (2-norm) tools/profile_scaling.jl:89-134 */
+int mgb_sum(mgb_vec x, double* out);                          /* sum(x) tools/profile_barrier.jl:45-59,95-114 */
+/* out[q] = M[q*K + k] of a row-major n x K device matrix: y[:, j] -> HPCVector, test/test_column_extract.jl:50 */
+int mgb_col_extract(mgb_vec M, int n, int K, int k, mgb_vec out);
 int mgb_mul(mgb_vec x, mgb_vec y, mgb_vec out);               /* w .* col, test_column_extract.jl:65 */
 int mgb_axpy(mgb_vec x, double alpha, mgb_vec y, mgb_vec out); /* out = x + alpha*y */
 int mgb_vec_allreduce_sum(mgb_vec x);                         /* sum over the ranks of a sharded context (no-op for world 1); MPI.Allreduce src:125 */
@@ -159,6 +173,9 @@ int mgb_amg_time_kernels(mgb_amg a, int level, int reps, double* ms7, double* by
 typedef struct mgb_plan_s* mgb_plan;  /* symbolic products of one level: R, B=D*R, B', Hessian plan T */
 int mgb_plan_create(mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D, int nq,
                     const int* idx_q, int idx_s, int level, mgb_plan* out);
+/* host-only: doubles of reduction scratch an AMG with n_local rows and at most max_level_unknowns (global, replicated)
+ * Newton unknowns per level allocates; the CPU suite checks it covers the 8-rank, 3-state-variable configurations */
+int mgb_reduction_scratch_doubles(int n_local, int max_level_unknowns, long long* out);
 int mgb_plan_destroy(mgb_plan p);
 int mgb_plan_sizes(mgb_plan p, int* N, int* nnz_lower, int* nnz_T, int* nnz_B);
 int mgb_plan_pattern(mgb_plan p, int32_t* rowptr, int32_t* colidx);

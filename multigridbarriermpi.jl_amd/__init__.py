@@ -35,7 +35,7 @@ __all__ = [
     "fem3d_mpi_solve", "parabolic_solve", "ParabolicSOL", "native_to_mpi",
     "mpi_to_native", "amgb", "Geometry", "AMGBSOL", "HPCVector", "HPCMatrix", "HPCSparseMatrix",
     "backend_hip", "amgb_zeros", "amgb_all_isfinite", "amgb_diag", "amgb_blockdiag", "map_rows", "map_rows_gpu",
-    "_raw_array", "_to_cpu_array", "MGBError", "device_count", "AMG", "amg",
+    "_raw_array", "_to_cpu_array", "MGBError", "device_count", "AMG", "amg", "hcat",
 ]
 
 
@@ -169,6 +169,16 @@ class HPCVector:
         call("mgb_dot", self.handle, other.handle, C.byref(out))
         return out.value
 
+    def norm(self) -> float:            # norm(x), tools/profile_scaling.jl:89-134
+        out = C.c_double()
+        call("mgb_norm", self.handle, C.byref(out))
+        return out.value
+
+    def sum(self) -> float:             # sum(x), tools/profile_barrier.jl:45-59
+        out = C.c_double()
+        call("mgb_sum", self.handle, C.byref(out))
+        return out.value
+
     def __mul__(self, other):          # w .* y  (test/test_column_extract.jl:65)
         if isinstance(other, HPCVector):
             out = HPCVector(self.n, self.backend)
@@ -210,8 +220,13 @@ class HPCMatrix:
         a = self.to_numpy()
         return a if dtype is None else a.astype(dtype)
 
-    def column(self, j: int) -> HPCVector:   # y[:, j] -> HPCVector (test/test_column_extract.jl:50)
-        return HPCVector(self.to_numpy()[:, j], self.backend)
+    def column(self, j: int) -> HPCVector:   # y[:, j] -> HPCVector (test/test_column_extract.jl:50), on the device
+        n, K = self.shape
+        if not 0 <= j < K:
+            raise IndexError("column index out of range")
+        out = HPCVector(n, self.backend)
+        call("mgb_col_extract", self._v.handle, n, K, int(j), out.handle)
+        return out
 
 
 def hpc_partition(m: int, world: int) -> np.ndarray:
@@ -253,31 +268,80 @@ def hpc_from_local_blocks(blocks) -> sp.csr_matrix:
 
 
 class HPCSparseMatrix:
-    """Device CSR matrix (reference HPCSparseMatrix local block, src:216-221).  A host copy of the
-    structure is kept for `mpi_to_native` (the reference gathers with SparseMatrixCSC(x), src:371)."""
+    """Device CSR matrix (reference HPCSparseMatrix local block, src:216-221).  The library keeps the structure it
+    uploaded; `.host` / `to_scipy()` read it back through the C ABI (the reference gathers with
+    SparseMatrixCSC(x), src:371).  `A @ B`, `A + B`, `A.T`, `hcat`, `amgb_blockdiag` are the library's setup-time
+    sparse algebra (mgb_csr_spgemm / add / transpose / hcat / blockdiag), not scipy."""
 
     def __init__(self, S, backend: Optional[HPCBackend] = None):
         S = sp.csr_matrix(S, dtype=np.float64)
         S.sort_indices()
         S.sum_duplicates()
-        self.host = S
         self.shape = S.shape
         self.backend = backend or backend_hip()
         h = C.c_void_p()
         rp, ci, va = i32(S.indptr), i32(S.indices), f64(S.data)
         call("mgb_csr_create", self.backend.handle, S.shape[0], S.shape[1], iptr(rp), iptr(ci), dptr(va), C.byref(h))
         self.handle = h
+        self._host = None
+
+    @classmethod
+    def _wrap(cls, handle, backend) -> "HPCSparseMatrix":
+        out = cls.__new__(cls)
+        r, c, nz = C.c_int(), C.c_int(), C.c_int()
+        call("mgb_csr_dims", handle, C.byref(r), C.byref(c), C.byref(nz))
+        out.shape, out.backend, out.handle, out._host = (r.value, c.value), backend, handle, None
+        return out
+
+    @property
+    def host(self) -> sp.csr_matrix:
+        """scipy copy of the matrix the library holds (fetched once through mgb_csr_get)."""
+        if self._host is None:
+            r, c, nz = C.c_int(), C.c_int(), C.c_int()
+            call("mgb_csr_dims", self.handle, C.byref(r), C.byref(c), C.byref(nz))
+            rp = np.empty(r.value + 1, dtype=np.int32)
+            ci = np.empty(nz.value, dtype=np.int32)
+            va = np.empty(nz.value)
+            call("mgb_csr_get", self.handle, iptr(rp), iptr(ci), dptr(va))
+            self._host = sp.csr_matrix((va, ci, rp), shape=(r.value, c.value))
+        return self._host
+
+    @property
+    def nnz(self) -> int:
+        nz = C.c_int()
+        call("mgb_csr_dims", self.handle, None, None, C.byref(nz))
+        return nz.value
 
     def __matmul__(self, x):
         if isinstance(x, HPCVector):                      # A * x  (test/test_nonsquare.jl:43)
             y = HPCVector(self.shape[0], self.backend)
             call("mgb_spmv", self.handle, x.handle, y.handle)
             return y
+        if isinstance(x, HPCSparseMatrix):                # A * B  (test/test_basic_ops.jl:39,55)
+            h = C.c_void_p()
+            call("mgb_csr_spgemm", self.handle, x.handle, C.byref(h))
+            return HPCSparseMatrix._wrap(h, self.backend)
         return NotImplemented
+
+    def __add__(self, other):                             # A + B  (test/test_matrix_addition.jl:48-63)
+        if not isinstance(other, HPCSparseMatrix):
+            return NotImplemented
+        h = C.c_void_p()
+        call("mgb_csr_add", self.handle, 1.0, other.handle, C.byref(h))
+        return HPCSparseMatrix._wrap(h, self.backend)
+
+    def __sub__(self, other):
+        if not isinstance(other, HPCSparseMatrix):
+            return NotImplemented
+        h = C.c_void_p()
+        call("mgb_csr_add", self.handle, -1.0, other.handle, C.byref(h))
+        return HPCSparseMatrix._wrap(h, self.backend)
 
     @property
     def T(self):                                            # lazy Adjoint in the reference; materialised here
-        return HPCSparseMatrix(self.host.T.tocsr(), self.backend)
+        h = C.c_void_p()
+        call("mgb_csr_transpose", self.handle, C.byref(h))
+        return HPCSparseMatrix._wrap(h, self.backend)
 
     def to_scipy(self):
         return self.host.copy()
@@ -296,6 +360,18 @@ class HPCSparseMatrix:
                 _lib.load().mgb_csr_free(self.handle)
         except Exception:
             pass
+
+
+def _csr_list_op(name: str, mats) -> "HPCSparseMatrix":
+    arr = (C.c_void_p * len(mats))(*[m.handle for m in mats])
+    h = C.c_void_p()
+    call(name, len(mats), arr, C.byref(h))
+    return HPCSparseMatrix._wrap(h, mats[0].backend)
+
+
+def hcat(*mats: "HPCSparseMatrix") -> "HPCSparseMatrix":
+    """hcat(M...) (D0 = hcat(op, Z): test/test_d0_construction.jl:92-100)."""
+    return _csr_list_op("mgb_csr_hcat", mats)
 
 
 # --------------------------------------------------------------------------- hooks (src:62-192)
@@ -327,19 +403,12 @@ def amgb_diag(like, z, m=None, n=None) -> HPCSparseMatrix:
     n = len(z) if n is None else n
     h = C.c_void_p()
     call("mgb_diag", backend.handle, z.handle, int(m), int(n), C.byref(h))
-    out = HPCSparseMatrix.__new__(HPCSparseMatrix)
-    zz = z.to_numpy()
-    d = min(m, n, len(zz))
-    out.host = sp.csr_matrix((zz[:d], (np.arange(d), np.arange(d))), shape=(m, n))
-    out.shape = (m, n)
-    out.backend = backend
-    out.handle = h
-    return out
+    return HPCSparseMatrix._wrap(h, backend)
 
 
 def amgb_blockdiag(*mats: HPCSparseMatrix) -> HPCSparseMatrix:
     """src:150."""
-    return HPCSparseMatrix(sp.block_diag([m.host for m in mats], format="csr"), mats[0].backend)
+    return _csr_list_op("mgb_csr_blockdiag", mats)
 
 
 def _raw_array(x):

@@ -50,10 +50,20 @@ PROTOTYPES = {
     "mgb_vec_download": [H, c_dbl_p],
     "mgb_csr_create": [H, C.c_int, C.c_int, c_i32_p, c_i32_p, c_dbl_p, C.POINTER(H)],
     "mgb_csr_free": [H],
+    "mgb_csr_dims": [H, c_int_p, c_int_p, c_int_p],
+    "mgb_csr_get": [H, c_i32_p, c_i32_p, c_dbl_p],
+    "mgb_csr_spgemm": [H, H, C.POINTER(H)],
+    "mgb_csr_transpose": [H, C.POINTER(H)],
+    "mgb_csr_add": [H, C.c_double, H, C.POINTER(H)],
+    "mgb_csr_hcat": [C.c_int, C.POINTER(H), C.POINTER(H)],
+    "mgb_csr_blockdiag": [C.c_int, C.POINTER(H), C.POINTER(H)],
     "mgb_diag": [H, H, C.c_int, C.c_int, C.POINTER(H)],
     "mgb_spmv": [H, H, H],
     "mgb_spmv_add": [H, H, H, H],
     "mgb_dot": [H, H, c_dbl_p],
+    "mgb_norm": [H, c_dbl_p],
+    "mgb_sum": [H, c_dbl_p],
+    "mgb_col_extract": [H, C.c_int, C.c_int, C.c_int, H],
     "mgb_mul": [H, H, H],
     "mgb_axpy": [H, C.c_double, H, H],
     "mgb_vec_allreduce_sum": [H],
@@ -87,6 +97,7 @@ PROTOTYPES = {
     "mgb_amg_time_kernels": [H, C.c_int, C.c_int, c_dbl_p, c_dbl_p],
     "mgb_plan_create": [H, C.c_int, c_str_arr, C.c_int, c_str_arr, C.c_int, c_int_p, C.c_int, C.c_int,
                         C.POINTER(H)],
+    "mgb_reduction_scratch_doubles": [C.c_int, C.c_int, c_ll_p],
     "mgb_plan_destroy": [H],
     "mgb_plan_sizes": [H, c_int_p, c_int_p, c_int_p, c_int_p],
     "mgb_plan_pattern": [H, c_i32_p, c_i32_p],

@@ -8,7 +8,7 @@
 namespace mgb {
 
 void hip_check(hipError_t e, const char* what) {
-  if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+  if (e != hipSuccess) throw HipError(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
 }
 
 static double now_s() {
@@ -18,8 +18,8 @@ static double now_s() {
 Ctx::Ctx(int dev) : device(dev) {
   int count = 0;
   hip_check(hipGetDeviceCount(&count), "hipGetDeviceCount");
-  if (count <= 0) throw std::runtime_error("mgb: no HIP device visible (the HIP path has no CPU fallback)");
-  if (dev < 0 || dev >= count) throw std::runtime_error("mgb: device id out of range");
+  if (count <= 0) throw HipError("mgb: no HIP device visible (the HIP path has no CPU fallback)");
+  if (dev < 0 || dev >= count) throw ArgError("mgb: device id out of range");
   hip_check(hipSetDevice(dev), "hipSetDevice");
   hip_check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
 }
@@ -30,10 +30,10 @@ Ctx::~Ctx() {
 
 void Ctx::allreduce_sum(double* dev_ptr, long long count) {
   if (world <= 1 || count <= 0) return;
-  if (!allreduce) throw std::runtime_error("mgb: sharded context without an allreduce callback");
+  if (!allreduce) throw ArgError("mgb: sharded context without an allreduce callback");
   hip_check(hipStreamSynchronize(stream), "sync before allreduce");
   const int rc = allreduce(allreduce_user, dev_ptr, count);
-  if (rc != 0) throw std::runtime_error("mgb: allreduce callback failed with code " + std::to_string(rc));
+  if (rc != 0) throw InternalError("mgb: allreduce callback failed with code " + std::to_string(rc));
   n_allreduce++;
   allreduce_bytes += 8.0 * count;
 }
@@ -41,10 +41,10 @@ void Ctx::allreduce_sum(double* dev_ptr, long long count) {
 // ------------------------------------------------------------------ row-block sharding
 
 void shard_rows(int rank, int world, int n, int block, int* r0, int* r1) {
-  if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("shard: bad rank / world");
-  if (block < 1 || n % block) throw std::runtime_error("shard: rows are not a multiple of the element block");
+  if (world < 1 || rank < 0 || rank >= world) throw ArgError("shard: bad rank / world");
+  if (block < 1 || n % block) throw ArgError("shard: rows are not a multiple of the element block");
   const long long nel = n / block;
-  if (nel < world) throw std::runtime_error("shard: fewer elements than ranks");
+  if (nel < world) throw ArgError("shard: fewer elements than ranks");
   *r0 = (int)(nel * rank / world) * block;
   *r1 = (int)(nel * (rank + 1) / world) * block;
 }
@@ -103,7 +103,7 @@ void DevCsrOwned::upload(const Csr& A) {
 static int state_index(const AmgSpec& spec, const std::string& name) {
   for (size_t i = 0; i < spec.state_variables.size(); ++i)
     if (spec.state_variables[i].first == name) return (int)i;
-  throw std::runtime_error("amg: D refers to unknown state variable '" + name + "'");
+  throw ArgError("amg: D refers to unknown state variable '" + name + "'");
 }
 
 Csr build_dstack(const GeometryHost& g, const AmgSpec& spec) {
@@ -113,8 +113,8 @@ Csr build_dstack(const GeometryHost& g, const AmgSpec& spec) {
   std::vector<int> off(K);
   for (int k = 0; k < K; ++k) {
     auto it = g.operators.find(spec.D[k].second);
-    if (it == g.operators.end()) throw std::runtime_error("amg: unknown operator '" + spec.D[k].second + "'");
-    if (it->second.rows != n || it->second.cols != n) throw std::runtime_error("amg: operator is not n x n");
+    if (it == g.operators.end()) throw ArgError("amg: unknown operator '" + spec.D[k].second + "'");
+    if (it->second.rows != n || it->second.cols != n) throw ArgError("amg: operator is not n x n");
     ops[k] = &it->second;
     off[k] = state_index(spec, spec.D[k].first) * n;
   }
@@ -137,9 +137,9 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
   std::vector<const Csr*> subs;
   for (auto& sv : spec.state_variables) {
     auto it = g.subspaces.find(sv.second);
-    if (it == g.subspaces.end()) throw std::runtime_error("amg: unknown subspace '" + sv.second + "'");
-    if (level < 0 || level >= (int)it->second.size()) throw std::runtime_error("amg: level out of range");
-    if (it->second[level].rows != n) throw std::runtime_error("amg: subspace matrix must have n rows");
+    if (it == g.subspaces.end()) throw ArgError("amg: unknown subspace '" + sv.second + "'");
+    if (level < 0 || level >= (int)it->second.size()) throw ArgError("amg: level out of range");
+    if (it->second[level].rows != n) throw ArgError("amg: subspace matrix must have n rows");
     subs.push_back(&it->second[level]);
   }
   pl.R = blockdiag(subs);
@@ -245,7 +245,7 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
         tot += c0;
       }
       cnt[nnzA] = tot;
-      if (tot > 2000000000LL) throw std::runtime_error("amg: Hessian plan exceeds Int32 indexing");
+      if (tot > 2000000000LL) throw ArgError("amg: Hessian plan exceeds Int32 indexing");
       for (int e = 0; e <= nnzA; ++e) pl.T.rowptr[e] = (int)cnt[e];
       pl.T.colidx.resize((size_t)tot);
       pl.T.vals.resize((size_t)tot);
@@ -290,16 +290,16 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
     : ctx_(ctx), n_(g.n), S_((int)spec.state_variables.size()), P_(P), spec_(spec) {
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
   if (const char* e = std::getenv("MGB_FUSED_TRIAL_ROWS")) fused_trial_rows_ = std::atoi(e);      // 0: never fuse
-  if (P.K != (int)spec.D.size()) throw std::runtime_error("amg: barrier K != number of D rows");
-  if (P.ncones < 1 || P.ncones > 2) throw std::runtime_error("amg: barrier supports 1 or 2 cones");
-  if (P.K > 8) throw std::runtime_error("amg: the barrier kernels support at most 8 rows of D");
+  if (P.K != (int)spec.D.size()) throw ArgError("amg: barrier K != number of D rows");
+  if (P.ncones < 1 || P.ncones > 2) throw ArgError("amg: barrier supports 1 or 2 cones");
+  if (P.K > 8) throw ArgError("amg: the barrier kernels support at most 8 rows of D");
   for (int ci = 0; ci < P.ncones; ++ci) {
     const ConeSpec& S = P.cone[ci];
-    if (S.nq < 1 || S.nq > 3) throw std::runtime_error("amg: barrier supports 1..3 gradient components");
+    if (S.nq < 1 || S.nq > 3) throw ArgError("amg: barrier supports 1..3 gradient components");
     for (int a = 0; a < S.nact(); ++a)
-      if (S.col(a) < 0 || S.col(a) >= P.K) throw std::runtime_error("amg: barrier index out of range");
+      if (S.col(a) < 0 || S.col(a) >= P.K) throw ArgError("amg: barrier index out of range");
   }
-  if ((int)g.w.size() != n_ || (int)g.x.size() != n_ * g.dim) throw std::runtime_error("amg: geometry x/w size mismatch");
+  if ((int)g.w.size() != n_ || (int)g.x.size() != n_ * g.dim) throw ArgError("amg: geometry x/w size mismatch");
   ng_ = g.n;
   Csr Dstack = build_dstack(g, spec);
   w_min_ = *std::min_element(g.w.begin(), g.w.end());      // global: every rank holds the whole geometry
@@ -327,7 +327,6 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
   phi_trial_.alloc((size_t)n_ * P.ncones);
   phi_trial2_.alloc((size_t)n_ * P.ncones);
   h_flag_.alloc(4);
-  partials_.alloc((size_t)2 * f0_blocks(n_) + 16);
   scal_.alloc(8);
   h_scal_.alloc(8);
   hip_check(hipMemsetAsync(c_.p, 0, c_.n * sizeof(double), ctx_.stream), "memset");
@@ -342,11 +341,20 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
     for (auto& sv : spec.state_variables) {
       auto it = g.subspaces.find(sv.second);
       if (it == g.subspaces.end() || l >= (int)it->second.size())
-        throw std::runtime_error("amg: unknown subspace '" + sv.second + "'");
+        throw ArgError("amg: unknown subspace '" + sv.second + "'");
       N += it->second[l].cols;
     }
     levels_[l]->plan.N = N;
   }
+  // reduction scratch: the objective kernels write two partials per block over the LOCAL rows, the dots one per block
+  // over the level's GLOBAL unknowns (replicated on every rank), which outgrow the local rows once world is large
+  int maxN = 0;
+  for (auto& lv : levels_) maxN = std::max(maxN, lv->plan.N);
+  partials_.alloc(reduction_scratch_doubles(n_, maxN));
+}
+
+size_t reduction_scratch_doubles(int n_local, int max_level_unknowns) {
+  return (size_t)2 * std::max(f0_blocks(n_local), f0_blocks(max_level_unknowns)) + 16;
 }
 
 Amg::Level& Amg::level(int l) {
@@ -623,6 +631,9 @@ bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, do
       (void)hipEventDestroy(e1);
     }
     *inc = h_scal_.p[3];
+    // the kernels only ever OR 1 into the flag: anything else is memory corruption, not a non-SPD Hessian
+    if (h_flag_.p[0] != 0 && h_flag_.p[0] != 1)
+      throw InternalError("gpuchol: pivot flag holds " + std::to_string(h_flag_.p[0]) + " (only 0 / 1 are ever written)");
     return h_flag_.p[0] == 0;
   }
   hip_check(hipMemcpyAsync(lv.h_avals.p, lv.avals.p, (size_t)nnzA * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
@@ -683,7 +694,7 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
     char buf[256];
     snprintf(buf, sizeof buf, "newton: infeasible start (level %d, t=%g, %d of %d rows outside the cone, min phi=%g at row %d, y=%g)",
              l, t, bad, n_, minphi, worst, y);
-    throw std::runtime_error(buf);
+    throw NumericError(buf);
   }
   double gnorm = dev_f1(lv, Dz_.p, t, lv.g.p);
   st.n_f1++;
@@ -838,7 +849,7 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
     bool ok0 = false;
     for (int attempt = 0; attempt < kInitialCenteringAttempts && !ok0; ++attempt)
       ok0 = amgb_step(t, lam_tol, opt.max_newton, its, st, opt.verbose);
-    if (!ok0) throw std::runtime_error("amgb: initial centering failed");
+    if (!ok0) throw NumericError("amgb: initial centering failed");
   }
   st.its.insert(st.its.end(), its.begin(), its.end());
   st.ts.push_back(t);
@@ -878,7 +889,7 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   }
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   st.t_elapsed = now_s() - t_begin;
-  if (t <= 1 / opt.tol) throw std::runtime_error("amgb: convergence failure (kappa collapsed)");
+  if (t <= 1 / opt.tol) throw NumericError("amgb: convergence failure (kappa collapsed)");
 }
 
 // ------------------------------------------------------------------ fine-grained entry points
@@ -935,6 +946,8 @@ bool Amg::solve_device(int l, const double* avals, const double* g, double* nste
   hip_check(hipMemcpyAsync(h_flag_.p, lv.gchol.fail_flag(), sizeof(int), hipMemcpyDeviceToHost, ctx_.stream), "D2H flag");
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   lv.nstep.download(nstep, lv.plan.N);
+  if (h_flag_.p[0] != 0 && h_flag_.p[0] != 1)
+    throw InternalError("gpuchol: pivot flag holds " + std::to_string(h_flag_.p[0]) + " (only 0 / 1 are ever written)");
   return h_flag_.p[0] == 0;
 }
 

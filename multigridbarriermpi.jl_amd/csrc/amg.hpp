@@ -121,6 +121,10 @@ void shard_rows(int rank, int world, int n, int block, int* r0, int* r1);
 LevelPlan shard_level_plan(const LevelPlan& full, int n, int S, int K, int nY, int r0, int r1);
 Csr shard_dstack(const Csr& Dstack, int n, int S, int K, int r0, int r1);
 
+// doubles of reduction scratch an Amg needs: two partials per block of the objective kernels over the local rows, one per
+// block of the dots over the (replicated, global) unknowns of the largest level
+size_t reduction_scratch_doubles(int n_local, int max_level_unknowns);
+
 Csr build_dstack(const GeometryHost& g, const AmgSpec& spec);
 LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr& Dstack, int level,
                            const BarrierParams& P);

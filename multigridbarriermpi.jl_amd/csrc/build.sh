@@ -6,15 +6,32 @@ OUT="$HERE/../lib"
 mkdir -p "$OUT" "$HERE/_obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 CXXFLAGS="-O3 -std=c++17 -fPIC -mavx2 -mfma -Wall -Wno-unused-result"
-for f in geometry mfchol; do
-  if [ "$HERE/$f.cpp" -nt "$HERE/_obj/$f.o" ] || [ "$HERE/sparse.hpp" -nt "$HERE/_obj/$f.o" ] || [ "$HERE/$f.hpp" -nt "$HERE/_obj/$f.o" ]; then
-    g++ $CXXFLAGS -c "$HERE/$f.cpp" -o "$HERE/_obj/$f.o" &
+HDRS=("$HERE"/*.hpp "$HERE/../../include/mgb_hip.h")
+pids=()
+# compile <object> <command...>: rebuild when the source or any header is newer; a stale object never survives a failed
+# compile (it is deleted first), and every background job's exit status is checked
+compile() {
+  local obj="$1" src="$2"; shift 2
+  local stale=0
+  [ -f "$obj" ] || stale=1
+  if [ $stale -eq 0 ]; then
+    for f in "$src" "${HDRS[@]}"; do [ "$f" -nt "$obj" ] && stale=1; done
   fi
+  if [ $stale -eq 1 ]; then
+    rm -f "$obj"
+    "$@" -c "$src" -o "$obj" &
+    pids+=($!)
+  fi
+}
+compile "$HERE/_obj/geometry.o" "$HERE/geometry.cpp" g++ $CXXFLAGS
+compile "$HERE/_obj/mfchol.o" "$HERE/mfchol.cpp" g++ $CXXFLAGS
+compile "$HERE/_obj/kernels.o" "$HERE/kernels.hip" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS
+compile "$HERE/_obj/gpuchol.o" "$HERE/gpuchol.hip" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS
+compile "$HERE/_obj/amg.o" "$HERE/amg.cpp" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS -x hip
+compile "$HERE/_obj/capi.o" "$HERE/capi.cpp" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS -x hip
+for pid in "${pids[@]}"; do
+  wait "$pid" || { echo "build.sh: a compile job failed" >&2; exit 1; }
 done
-"$HIPCC" --offload-arch=gfx950 $CXXFLAGS -c "$HERE/kernels.hip" -o "$HERE/_obj/kernels.o" &
-"$HIPCC" --offload-arch=gfx950 $CXXFLAGS -c "$HERE/gpuchol.hip" -o "$HERE/_obj/gpuchol.o" &
-"$HIPCC" --offload-arch=gfx950 $CXXFLAGS -x hip -c "$HERE/amg.cpp" -o "$HERE/_obj/amg.o" &
-"$HIPCC" --offload-arch=gfx950 $CXXFLAGS -x hip -c "$HERE/capi.cpp" -o "$HERE/_obj/capi.o" &
-wait
+rm -f "$OUT/libmgb_hip.so"
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libmgb_hip.so" "$HERE"/_obj/{geometry,mfchol,kernels,gpuchol,amg,capi}.o -lpthread
 echo "built $OUT/libmgb_hip.so"

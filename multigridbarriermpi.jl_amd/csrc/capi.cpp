@@ -25,6 +25,7 @@ struct mgb_vec_s {
 struct mgb_csr_s {
   mgb_ctx_s* ctx;
   DevCsrOwned A;
+  Csr host;      // structure + values as uploaded: SparseMatrixCSC(x) gathers (src:371) and the setup-time sparse algebra
 };
 struct mgb_amg_s {
   mgb_ctx_s* ctx;
@@ -47,22 +48,22 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+// exception firewall: the status code comes from the exception TYPE (errors.hpp), never from its message
 template <class F>
 int guard(F&& fn) {
   try {
     fn();
     return MGB_OK;
-  } catch (const std::invalid_argument& e) {
+  } catch (const HipError& e) {
+    return fail(MGB_E_HIP, e.what());
+  } catch (const NumericError& e) {
+    return fail(MGB_E_NUMERIC, e.what());
+  } catch (const std::invalid_argument& e) {      // ArgError and need()
     return fail(MGB_E_ARG, e.what());
   } catch (const std::out_of_range& e) {
     return fail(MGB_E_ARG, e.what());
-  } catch (const std::runtime_error& e) {
-    const std::string m = e.what();
-    int code = MGB_E_INTERNAL;
-    if (m.find("HIP") != std::string::npos || m.find("no HIP device") != std::string::npos) code = MGB_E_HIP;
-    else if (m.rfind("amg:", 0) == 0 || m.rfind("fem", 0) == 0 || m.find("CSR") != std::string::npos || m.rfind("hcat", 0) == 0) code = MGB_E_ARG;
-    else if (m.rfind("amgb:", 0) == 0 || m.rfind("newton:", 0) == 0 || m.rfind("MfChol", 0) == 0) code = MGB_E_NUMERIC;
-    return fail(code, m);
+  } catch (const std::bad_alloc&) {
+    return fail(MGB_E_INTERNAL, "out of host memory");
   } catch (const std::exception& e) {
     return fail(MGB_E_INTERNAL, e.what());
   } catch (...) {
@@ -174,6 +175,35 @@ BarrierParams make_params(int K, int nq, const int* idx_q, int idx_s, double p) 
   int iq3[3] = {0, 0, 0};
   for (int i = 0; i < nq; ++i) iq3[i] = idx_q[i];
   return make_params_cones(K, 1, &nq, iq3, &idx_s, nullptr, &p);
+}
+
+mgb_csr_s* new_csr(mgb_ctx_s* ctx, Csr&& A) {
+  hip_check(hipSetDevice(ctx->ctx.device), "hipSetDevice");
+  auto* m = new mgb_csr_s{ctx, {}, {}};
+  try {
+    m->A.upload(A);
+    m->host = std::move(A);
+  } catch (...) {
+    delete m;
+    throw;
+  }
+  return m;
+}
+
+// one scalar reduction of a device vector through `launch` (dot / sum), result on the host
+template <class Launch>
+double reduce_scalar(mgb_vec x, Launch&& launch) {
+  if (x->n == 0) return 0.0;
+  hipStream_t st = x->ctx->ctx.stream;
+  const int nb = f0_blocks(x->n);
+  DevBuf<double> scratch;
+  scratch.alloc((size_t)nb + 1);
+  launch(st, scratch.p, scratch.p + nb);
+  hip_check(hipGetLastError(), "reduction launch");
+  hip_check(hipStreamSynchronize(st), "sync reduction");
+  double out = 0.0;
+  hip_check(hipMemcpy(&out, scratch.p + nb, sizeof(double), hipMemcpyDeviceToHost), "D2H");
+  return out;
 }
 
 }  // namespace
@@ -376,18 +406,68 @@ int mgb_csr_create(mgb_ctx ctx, int rows, int cols, const int32_t* rowptr, const
     need(ctx && out, "null argument");
     hip_check(hipSetDevice(ctx->ctx.device), "hipSetDevice");
     Csr A = make_csr(rows, cols, rowptr, colidx, vals, "mgb_csr_create");
-    auto* m = new mgb_csr_s{ctx, {}};
-    try {
-      m->A.upload(A);
-    } catch (...) {
-      delete m;
-      throw;
-    }
-    *out = m;
+    *out = new_csr(ctx, std::move(A));
   });
 }
 int mgb_csr_free(mgb_csr A) {
   return guard([&] { delete A; });
+}
+int mgb_csr_dims(mgb_csr A, int* rows, int* cols, int* nnz) {
+  return guard([&] {
+    need(A, "null argument");
+    if (rows) *rows = A->host.rows;
+    if (cols) *cols = A->host.cols;
+    if (nnz) *nnz = A->host.nnz();
+  });
+}
+int mgb_csr_get(mgb_csr A, int32_t* rowptr, int32_t* colidx, double* vals) {
+  return guard([&] {
+    need(A, "null argument");
+    if (rowptr) std::copy(A->host.rowptr.begin(), A->host.rowptr.end(), rowptr);
+    if (colidx) std::copy(A->host.colidx.begin(), A->host.colidx.end(), colidx);
+    if (vals) std::copy(A->host.vals.begin(), A->host.vals.end(), vals);
+  });
+}
+int mgb_csr_spgemm(mgb_csr A, mgb_csr B, mgb_csr* out) {
+  return guard([&] {
+    need(A && B && out, "null argument");
+    *out = new_csr(A->ctx, spgemm(A->host, B->host));
+  });
+}
+int mgb_csr_transpose(mgb_csr A, mgb_csr* out) {
+  return guard([&] {
+    need(A && out, "null argument");
+    *out = new_csr(A->ctx, transpose(A->host));
+  });
+}
+int mgb_csr_add(mgb_csr A, double alpha, mgb_csr B, mgb_csr* out) {
+  return guard([&] {
+    need(A && B && out, "null argument");
+    *out = new_csr(A->ctx, add(A->host, alpha, B->host));
+  });
+}
+static std::vector<const Csr*> host_list(int count, const mgb_csr* mats) {
+  need(count >= 1 && mats, "empty matrix list");
+  std::vector<const Csr*> v;
+  for (int i = 0; i < count; ++i) {
+    need(mats[i] != nullptr, "null matrix in list");
+    v.push_back(&mats[i]->host);
+  }
+  return v;
+}
+int mgb_csr_hcat(int count, const mgb_csr* mats, mgb_csr* out) {
+  return guard([&] {
+    need(out, "null argument");
+    auto v = host_list(count, mats);
+    *out = new_csr(mats[0]->ctx, hcat(v));
+  });
+}
+int mgb_csr_blockdiag(int count, const mgb_csr* mats, mgb_csr* out) {
+  return guard([&] {
+    need(out, "null argument");
+    auto v = host_list(count, mats);
+    *out = new_csr(mats[0]->ctx, blockdiag(v));
+  });
 }
 int mgb_diag(mgb_ctx ctx, mgb_vec z, int m, int n, mgb_csr* out) {
   return guard([&] {
@@ -404,14 +484,7 @@ int mgb_diag(mgb_ctx ctx, mgb_vec z, int m, int n, mgb_csr* out) {
       }
       A.rowptr[i + 1] = (int)A.colidx.size();
     }
-    auto* M = new mgb_csr_s{ctx, {}};
-    try {
-      M->A.upload(A);
-    } catch (...) {
-      delete M;
-      throw;
-    }
-    *out = M;
+    *out = new_csr(ctx, std::move(A));
   });
 }
 int mgb_spmv_add(mgb_csr A, mgb_vec x, mgb_vec y0, mgb_vec y) {
@@ -426,13 +499,27 @@ int mgb_spmv(mgb_csr A, mgb_vec x, mgb_vec y) { return mgb_spmv_add(A, x, nullpt
 int mgb_dot(mgb_vec x, mgb_vec y, double* out) {
   return guard([&] {
     need(x && y && out && x->n == y->n, "dot: shape mismatch");
-    hipStream_t st = x->ctx->ctx.stream;
-    DevBuf<double> scratch;
-    scratch.alloc((size_t)f0_blocks(x->n) + 1);
-    launch_dot(st, x->n, x->buf.p, y->buf.p, scratch.p, scratch.p + f0_blocks(x->n));
-    hip_check(hipStreamSynchronize(st), "sync dot");
-    hip_check(hipMemcpy(out, scratch.p + f0_blocks(x->n), sizeof(double), hipMemcpyDeviceToHost), "D2H");
-    if (x->n == 0) *out = 0.0;
+    *out = reduce_scalar(x, [&](hipStream_t st, double* parts, double* res) { launch_dot(st, x->n, x->buf.p, y->buf.p, parts, res); });
+  });
+}
+int mgb_norm(mgb_vec x, double* out) {
+  return guard([&] {
+    need(x && out, "null argument");
+    *out = std::sqrt(reduce_scalar(x, [&](hipStream_t st, double* parts, double* res) { launch_dot(st, x->n, x->buf.p, x->buf.p, parts, res); }));
+  });
+}
+int mgb_sum(mgb_vec x, double* out) {
+  return guard([&] {
+    need(x && out, "null argument");
+    *out = reduce_scalar(x, [&](hipStream_t st, double* parts, double* res) { launch_sum(st, x->n, x->buf.p, parts, res); });
+  });
+}
+int mgb_col_extract(mgb_vec M, int n, int K, int k, mgb_vec out) {
+  return guard([&] {
+    need(M && out && n >= 0 && K >= 1 && k >= 0 && k < K, "col_extract: bad arguments");
+    need((long long)n * K == M->n && out->n == n, "col_extract: shape mismatch");
+    launch_col_extract(M->ctx->ctx.stream, n, K, k, M->buf.p, out->buf.p);
+    hip_check(hipGetLastError(), "col_extract launch");
   });
 }
 int mgb_mul(mgb_vec x, mgb_vec y, mgb_vec out) {
@@ -598,13 +685,13 @@ int mgb_amg_f2(mgb_amg a, int level, const double* s, double t, double* lower_va
 int mgb_amg_solve_linear(mgb_amg a, int level, const double* lower_vals, const double* g, double* x) {
   return guard([&] {
     need(a && lower_vals && g && x && level >= 0 && level < a->amg->L(), "solve_linear: bad arguments");
-    if (!a->amg->solve_host(level, lower_vals, g, x)) throw std::runtime_error("MfChol: matrix is not positive definite");
+    if (!a->amg->solve_host(level, lower_vals, g, x)) throw NumericError("MfChol: matrix is not positive definite");
   });
 }
 int mgb_amg_solve_linear_gpu(mgb_amg a, int level, const double* lower_vals, const double* g, double* x) {
   return guard([&] {
     need(a && lower_vals && g && x && level >= 0 && level < a->amg->L(), "solve_linear_gpu: bad arguments");
-    if (!a->amg->solve_device(level, lower_vals, g, x)) throw std::runtime_error("MfChol: matrix is not positive definite");
+    if (!a->amg->solve_device(level, lower_vals, g, x)) throw NumericError("MfChol: matrix is not positive definite");
   });
 }
 int mgb_amg_set_solver(mgb_amg a, int host) {
@@ -699,6 +786,12 @@ int mgb_plan_create(mgb_geo g, int S, const char* const* state_vars, int K, cons
     *out = p;
   });
 }
+int mgb_reduction_scratch_doubles(int n_local, int max_level_unknowns, long long* out) {
+  return guard([&] {
+    need(out && n_local >= 0 && max_level_unknowns >= 0, "reduction_scratch: bad arguments");
+    *out = (long long)reduction_scratch_doubles(n_local, max_level_unknowns);
+  });
+}
 int mgb_plan_destroy(mgb_plan p) {
   return guard([&] { delete p; });
 }
@@ -765,7 +858,7 @@ int mgb_plan_chol_bench(mgb_plan p, const double* Y, int dim, int reps, double* 
     ch.analyze(pl.Apat, pl.coords.data(), dim);
     auto t0 = std::chrono::steady_clock::now();
     for (int r = 0; r < reps; ++r)
-      if (!ch.factor(vals.data())) throw std::runtime_error("MfChol: bench matrix not SPD");
+      if (!ch.factor(vals.data())) throw NumericError("MfChol: bench matrix not SPD");
     const double tf = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
     const int N = pl.N;
     std::vector<double> xs(N), b(N, 0.0);
@@ -831,7 +924,7 @@ int mgb_chol_selftest(int nx, int ny, double* max_residual, double* flops, doubl
     MfChol ch;
     ch.analyze(Lo, coords.data(), 2);
     const auto t0 = std::chrono::steady_clock::now();
-    if (!ch.factor(Lo.vals.data())) throw std::runtime_error("MfChol: selftest matrix not SPD");
+    if (!ch.factor(Lo.vals.data())) throw NumericError("MfChol: selftest matrix not SPD");
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::vector<double> xs(N), b(N, 0.0);
     for (int i = 0; i < N; ++i) xs[i] = std::sin(0.37 * i) + 0.1;

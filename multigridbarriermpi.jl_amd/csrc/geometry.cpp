@@ -15,7 +15,7 @@
 namespace mgb {
 
 GeometryHost fem1d_native(int L) {
-  if (L < 1 || L > 24) throw std::runtime_error("fem1d: L out of range");
+  if (L < 1 || L > 24) throw ArgError("fem1d: L out of range");
   GeometryHost g;
   g.dim = 1;
   g.block = 2;
@@ -114,13 +114,13 @@ struct Tri {
 }  // namespace
 
 GeometryHost fem2d_native(int L, const double* K, int nK_rows) {
-  if (L < 1 || L > 14) throw std::runtime_error("fem2d: L out of range");
+  if (L < 1 || L > 14) throw ArgError("fem2d: L out of range");
   static const double Kdef[12] = {-1, -1, 1, -1, -1, 1, 1, -1, 1, 1, -1, 1};
   if (!K) {
     K = Kdef;
     nK_rows = 6;
   }
-  if (nK_rows % 3 != 0 || nK_rows < 3) throw std::runtime_error("fem2d: K must have 3m rows");
+  if (nK_rows % 3 != 0 || nK_rows < 3) throw ArgError("fem2d: K must have 3m rows");
   GeometryHost g;
   g.dim = 2;
   g.block = 7;
@@ -199,7 +199,7 @@ GeometryHost fem2d_native(int L, const double* K, int nK_rows) {
     }
     const double e1x = p2[0] - p1[0], e1y = p2[1] - p1[1], e2x = p3[0] - p1[0], e2y = p3[1] - p1[1];
     const double det = e1x * e2y - e1y * e2x;
-    if (det == 0) throw std::runtime_error("fem2d: degenerate triangle");
+    if (det == 0) throw ArgError("fem2d: degenerate triangle");
     const double area = std::fabs(det) / 2;
     const double xix = e2y / det, xiy = -e2x / det, etx = -e1y / det, ety = e1x / det;
     for (int i = 0; i < 7; ++i) {
@@ -367,8 +367,8 @@ struct Lag1d {
 }  // namespace
 
 GeometryHost fem3d_native(int L, int k) {
-  if (L < 1 || L > 8) throw std::runtime_error("fem3d: L out of range");
-  if (k < 1 || k > 3) throw std::runtime_error("fem3d: k must be 1, 2 or 3");
+  if (L < 1 || L > 8) throw ArgError("fem3d: L out of range");
+  if (k < 1 || k > 3) throw ArgError("fem3d: k must be 1, 2 or 3");
   const Lag1d lg(k);
   const int m1 = k + 1, nloc = m1 * m1 * m1;
   const double wq1[3][4] = {{0.5, 0.5, 0, 0}, {1.0 / 6, 4.0 / 6, 1.0 / 6, 0}, {1.0 / 8, 3.0 / 8, 3.0 / 8, 1.0 / 8}};
@@ -480,7 +480,7 @@ GeometryHost fem3d_native(int L, int k) {
     const int nel = (int)El.size();
     const int npts = k * (1 << l) + 1;
     const long long ntot = (long long)npts * npts * npts;
-    if (ntot > 2000000000LL) throw std::runtime_error("fem3d: too many continuous dofs for Int32");
+    if (ntot > 2000000000LL) throw ArgError("fem3d: too many continuous dofs for Int32");
     std::vector<int> dmap((size_t)ntot, -1);
     int md = 0;
     for (int c = 0; c < npts; ++c)

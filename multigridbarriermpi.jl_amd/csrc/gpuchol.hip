@@ -32,7 +32,7 @@ constexpr int TB = 256;      // threads per workgroup (factorisation kernels)
 constexpr int RT = 1024;     // threads per workgroup (backward_rect)
 
 void ck(hipError_t e, const char* what) {
-  if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in gpuchol ") + what + ": " + hipGetErrorString(e));
+  if (e != hipSuccess) throw HipError(std::string("HIP error in gpuchol ") + what + ": " + hipGetErrorString(e));
 }
 
 // optional phase stamps (100 MHz wall clock) of workgroup 0 of every factorisation launch: MGB_CHOL_PROF=1
@@ -879,13 +879,13 @@ void GpuChol::build(const MfChol& sym) {
     g.child[0] = nd.children.size() > 0 ? nd.children[0] : -1;
     g.child[1] = nd.children.size() > 1 ? nd.children[1] : -1;
     g.iofs = -1;
-    if (nd.children.size() > 2) throw std::runtime_error("gpuchol: elimination tree is not binary");
+    if (nd.children.size() > 2) throw InternalError("gpuchol: elimination tree is not binary");
     bdry_all.insert(bdry_all.end(), nd.bdry.begin(), nd.bdry.end());
     ea_all.insert(ea_all.end(), nd.ea.begin(), nd.ea.end());
-    if (nd.parent >= 0 && nd.ea.size() != nd.bdry.size()) throw std::runtime_error("gpuchol: ea/bdry size mismatch");
-    if (nd.parent >= 0 && !std::is_sorted(nd.ea.begin(), nd.ea.end())) throw std::runtime_error("gpuchol: ea not ascending");
+    if (nd.parent >= 0 && nd.ea.size() != nd.bdry.size()) throw InternalError("gpuchol: ea/bdry size mismatch");
+    if (nd.parent >= 0 && !std::is_sorted(nd.ea.begin(), nd.ea.end())) throw InternalError("gpuchol: ea not ascending");
     if (nd.parent < 0) ea_all.resize(bdry_all.size(), 0);
-    if ((long long)(g.nf + 1) * (g.nf + 1) > 2000000000LL) throw std::runtime_error("gpuchol: front too large");
+    if ((long long)(g.nf + 1) * (g.nf + 1) > 2000000000LL) throw ArgError("gpuchol: front too large");
     off += (long long)(g.nf + 1) * (g.nf + 1);
     max_nf_ = std::max(max_nf_, g.nf);
     for (int c : nd.children) height[t] = std::max(height[t], height[c] + 1);   // postorder: children first
@@ -904,7 +904,7 @@ void GpuChol::build(const MfChol& sym) {
       const int cnb = nodes[c].nf - nodes[c].ns;
       const int* ea = ea_all.data() + nodes[c].bofs;
       for (int a = 0; a < cnb; ++a) {
-        if (ea[a] < 0 || ea[a] >= g.nf || iv[ea[a]] != -1) throw std::runtime_error("gpuchol: bad extend-add map");
+        if (ea[a] < 0 || ea[a] >= g.nf || iv[ea[a]] != -1) throw InternalError("gpuchol: bad extend-add map");
         iv[ea[a]] = a;
       }
       iv[g.nf] = cnb;
@@ -929,7 +929,7 @@ void GpuChol::build(const MfChol& sym) {
     size_t q = 0;
     for (int ch = 0; ch < nch; ++ch) {
       const int nrb = (nf + 1 - ch * PB + TB - 1) / TB;      // rows ch*32 .. nf inclusive
-      if (nrb > 65535) throw std::runtime_error("gpuchol: front too large for the start-job key");
+      if (nrb > 65535) throw ArgError("gpuchol: front too large for the start-job key");
       for (int rb = 0; rb < nrb; ++rb) {
         StartJob j{};
         j.node = t;
@@ -938,7 +938,7 @@ void GpuChol::build(const MfChol& sym) {
         j.a0 = (int)asrc.size();
         while (q < m && key(ord[q]) == (long long)ch * 65536 + rb) {
           const int pos = sym.a_pos_[t][ord[q]], col = pos / nf, row = pos % nf;
-          if (row < col) throw std::runtime_error("gpuchol: assembly entry above the diagonal");
+          if (row < col) throw InternalError("gpuchol: assembly entry above the diagonal");
           asrc.push_back(sym.a_idx_[t][ord[q]]);
           apos.push_back(ld * col + row);
           ++q;
@@ -947,7 +947,7 @@ void GpuChol::build(const MfChol& sym) {
         sjobs[t].push_back(j);
       }
     }
-    if (q != m) throw std::runtime_error("gpuchol: assembly entry outside the front");
+    if (q != m) throw InternalError("gpuchol: assembly entry outside the front");
     nodes[t].a0 = sjobs[t].empty() ? 0 : sjobs[t].front().a0;
     nodes[t].a1 = sjobs[t].empty() ? 0 : sjobs[t].back().a1;
   }
@@ -1042,7 +1042,7 @@ void GpuChol::build(const MfChol& sym) {
             continue;
           }
           const int Tr = (g.nf + 1 - k1 + TS - 1) / TS, Tc = std::max(1, (g.nf - k1 + TS - 1) / TS);
-          if (Tr > 30000) throw std::runtime_error("gpuchol: front too large for tile index");
+          if (Tr > 30000) throw ArgError("gpuchol: front too large for tile index");
           for (int ti = 0; ti < Tr; ++ti)
             for (int tj = 0; tj <= std::min(ti, Tc - 1); ++tj) {
               st.ti = (short)ti;
@@ -1099,7 +1099,7 @@ void GpuChol::build(const MfChol& sym) {
     hp.rect.cnt = (int)rects.size() - hp.rect.ofs;
     launches_ += 1 + (hp.rect.cnt ? 1 : 0);
   }
-  if ((size_t)(max_nf_ + RT + PB) * 8 > 150 * 1024) throw std::runtime_error("gpuchol: front exceeds the LDS budget of the sweeps");
+  if ((size_t)(max_nf_ + RT + PB) * 8 > 150 * 1024) throw ArgError("gpuchol: front exceeds the LDS budget of the sweeps");
   d_nodes_ = upload(nodes);
   d_perm_ = upload(sym.perm_);
   d_bdry_ = upload(bdry_all);
@@ -1129,14 +1129,11 @@ void GpuChol::build(const MfChol& sym) {
     allocs_.push_back(d_prof_);
     ck(hipMemset(d_prof_, 0, (size_t)8 * launches_ * sizeof(long long)), "memset prof");
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    ck(hipFuncSetAttribute((const void*)backward_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
-    ck(hipFuncSetAttribute((const void*)backward_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
-    ck(hipFuncSetAttribute((const void*)backward_rect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
-    ck(hipFuncSetAttribute((const void*)front_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024), "attr");
-    attr_done = true;
-  }
+  // per device (function attributes do not carry over to another GPU of the same process): set on every build
+  ck(hipFuncSetAttribute((const void*)backward_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
+  ck(hipFuncSetAttribute((const void*)backward_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
+  ck(hipFuncSetAttribute((const void*)backward_rect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
+  ck(hipFuncSetAttribute((const void*)front_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024), "attr");
 }
 
 // The whole chain is launch-bound (83 dependent launches at fem2d L=7), so it is captured once per

@@ -389,6 +389,14 @@ __global__ __launch_bounds__(kBlock) void dot_kernel(int n, const double* __rest
   if (threadIdx.x == 0) partials[blockIdx.x] = r;
 }
 
+__global__ __launch_bounds__(kBlock) void sum_kernel(int n, const double* __restrict__ x, double* partials) {
+  __shared__ double lds[kBlock / 64];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) acc += x[i];
+  double r = block_sum(acc, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
 __global__ __launch_bounds__(kBlock) void isfinite_kernel(int n, const double* __restrict__ x, int* flag) {
   int bad = 0;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
@@ -453,6 +461,12 @@ void launch_barrier_f2(hipStream_t st, int n, BarrierParams P, const double* Dz,
 void launch_dot(hipStream_t st, int n, const double* x, const double* y, double* partials, double* out) {
   const int grid = grid_for(n);
   hipLaunchKernelGGL(dot_kernel, dim3(grid), dim3(kBlock), 0, st, n, x, y, partials);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, grid, 1, partials, out);
+}
+
+void launch_sum(hipStream_t st, int n, const double* x, double* partials, double* out) {
+  const int grid = grid_for(n);
+  hipLaunchKernelGGL(sum_kernel, dim3(grid), dim3(kBlock), 0, st, n, x, partials);
   hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, grid, 1, partials, out);
 }
 

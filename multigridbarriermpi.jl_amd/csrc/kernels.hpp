@@ -67,6 +67,8 @@ void launch_barrier_f1(hipStream_t st, int n, BarrierParams P, const double* Dz,
 void launch_barrier_f2(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, double* Y);
 // out[0] = sum x_i y_i ; partials scratch of f0_blocks(n) doubles
 void launch_dot(hipStream_t st, int n, const double* x, const double* y, double* partials, double* out);
+// out[0] = sum x_i ; partials scratch of f0_blocks(n) doubles
+void launch_sum(hipStream_t st, int n, const double* x, double* partials, double* out);
 // flag[0] = 1 if all finite else 0
 void launch_all_isfinite(hipStream_t st, int n, const double* x, int* flag);
 // out = x .* y

@@ -319,7 +319,7 @@ int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const do
 
 void MfChol::analyze(const Csr& Ain, const double* coords, int dim, int leaf_size) {
   if (const char* e = std::getenv("MGB_LEAF")) leaf_size = std::max(8, std::atoi(e));      // tuning knob
-  if (Ain.rows != Ain.cols) throw std::runtime_error("MfChol: matrix not square");
+  if (Ain.rows != Ain.cols) throw ArgError("MfChol: matrix not square");
   n_ = Ain.rows;
   // symmetric adjacency (pattern + transpose) for ordering and the symbolic phase
   Csr A;
@@ -391,11 +391,11 @@ void MfChol::analyze(const Csr& Ain, const double* coords, int dim, int leaf_siz
   }
   auto pos_in = [&](const Node& p, int i) -> int {
     if (i < p.first + p.ns) {
-      if (i < p.first) throw std::runtime_error("MfChol: index below front");
+      if (i < p.first) throw InternalError("MfChol: index below front");
       return i - p.first;
     }
     auto it = std::lower_bound(p.bdry.begin(), p.bdry.end(), i);
-    if (it == p.bdry.end() || *it != i) throw std::runtime_error("MfChol: index missing from parent front");
+    if (it == p.bdry.end() || *it != i) throw InternalError("MfChol: index missing from parent front");
     return p.ns + (int)(it - p.bdry.begin());
   };
   for (size_t t = 0; t < nodes_.size(); ++t) {
@@ -404,7 +404,7 @@ void MfChol::analyze(const Csr& Ain, const double* coords, int dim, int leaf_siz
     if (nd.parent >= 0)
       for (int i : nd.bdry) nd.ea.push_back(pos_in(nodes_[nd.parent], i));
     else if (!nd.bdry.empty())
-      throw std::runtime_error("MfChol: root with boundary");
+      throw InternalError("MfChol: root with boundary");
   }
   // assembly map
   a_idx_.assign(nodes_.size(), {});

@@ -12,6 +12,8 @@
 #include <string>
 #include <vector>
 
+#include "errors.hpp"
+
 namespace mgb {
 
 struct Csr {
@@ -77,7 +79,7 @@ inline Csr transpose(const Csr& A) {
 // only when drop_zeros (the reference hit a cancellation-dependent sparsity bug,
 // test/test_matrix_addition.jl:21-24: patterns here are structural by default).
 inline Csr spgemm(const Csr& A, const Csr& B, bool drop_zeros = false) {
-  if (A.cols != B.rows) throw std::runtime_error("spgemm: dimension mismatch");
+  if (A.cols != B.rows) throw ArgError("spgemm: dimension mismatch");
   Csr C(A.rows, B.cols);
   std::vector<int> mark(B.cols, -1);
   std::vector<double> acc(B.cols, 0.0);
@@ -112,7 +114,7 @@ inline Csr spgemm(const Csr& A, const Csr& B, bool drop_zeros = false) {
 inline Csr hcat(const std::vector<const Csr*>& blocks) {
   int rows = blocks[0]->rows, cols = 0;
   for (auto* b : blocks) {
-    if (b->rows != rows) throw std::runtime_error("hcat: row mismatch");
+    if (b->rows != rows) throw ArgError("hcat: row mismatch");
     cols += b->cols;
   }
   Csr C(rows, cols);
@@ -153,9 +155,31 @@ inline Csr blockdiag(const std::vector<const Csr*>& blocks) {
   return C;
 }
 
+// C = A + alpha * B on the union pattern (reference: the K^2 - 1 sparse adds of the Hessian recipe,
+// test/test_matrix_addition.jl:48-63); structural: entries that cancel to 0 stay in the pattern
+inline Csr add(const Csr& A, double alpha, const Csr& B) {
+  if (A.rows != B.rows || A.cols != B.cols) throw ArgError("add: shape mismatch");
+  Csr C(A.rows, A.cols);
+  for (int r = 0; r < A.rows; ++r) {
+    int i = A.rowptr[r], j = B.rowptr[r];
+    const int ie = A.rowptr[r + 1], je = B.rowptr[r + 1];
+    while (i < ie || j < je) {
+      const int ca = i < ie ? A.colidx[i] : A.cols, cb = j < je ? B.colidx[j] : A.cols;
+      const int c = std::min(ca, cb);
+      double v = 0.0;
+      if (ca == c) v += A.vals[i++];
+      if (cb == c) v += alpha * B.vals[j++];
+      C.colidx.push_back(c);
+      C.vals.push_back(v);
+    }
+    C.rowptr[r + 1] = (int)C.colidx.size();
+  }
+  return C;
+}
+
 // rows [r0, r1) of A (row-block shard)
 inline Csr row_block(const Csr& A, int r0, int r1) {
-  if (r0 < 0 || r1 > A.rows || r0 > r1) throw std::runtime_error("row_block: bad range");
+  if (r0 < 0 || r1 > A.rows || r0 > r1) throw ArgError("row_block: bad range");
   Csr B(r1 - r0, A.cols);
   const int b = A.rowptr[r0], e = A.rowptr[r1];
   B.colidx.assign(A.colidx.begin() + b, A.colidx.begin() + e);
@@ -169,7 +193,7 @@ inline Csr row_select(const Csr& A, const std::vector<int>& pick) {
   Csr B((int)pick.size(), A.cols);
   for (size_t i = 0; i < pick.size(); ++i) {
     const int r = pick[i];
-    if (r < 0 || r >= A.rows) throw std::runtime_error("row_select: row out of range");
+    if (r < 0 || r >= A.rows) throw ArgError("row_select: row out of range");
     B.colidx.insert(B.colidx.end(), A.colidx.begin() + A.rowptr[r], A.colidx.begin() + A.rowptr[r + 1]);
     B.vals.insert(B.vals.end(), A.vals.begin() + A.rowptr[r], A.vals.begin() + A.rowptr[r + 1]);
     B.rowptr[i + 1] = (int)B.colidx.size();
@@ -181,13 +205,13 @@ inline Csr row_select(const Csr& A, const std::vector<int>& pick) {
 // `strict`, rejected (an operator that couples rows of different shards cannot be row-block sharded).
 // The map must be increasing on the kept columns, so rows stay sorted.
 inline Csr col_remap(const Csr& A, const std::vector<int>& map, int newcols, bool strict) {
-  if ((int)map.size() != A.cols) throw std::runtime_error("col_remap: map size mismatch");
+  if ((int)map.size() != A.cols) throw ArgError("col_remap: map size mismatch");
   Csr B(A.rows, newcols);
   for (int r = 0; r < A.rows; ++r) {
     for (int k = A.rowptr[r]; k < A.rowptr[r + 1]; ++k) {
       const int c = map[A.colidx[k]];
       if (c < 0) {
-        if (strict) throw std::runtime_error("col_remap: entry couples two shards (operator is not element-local)");
+        if (strict) throw ArgError("col_remap: entry couples two shards (operator is not element-local)");
         continue;
       }
       B.colidx.push_back(c);
@@ -209,12 +233,12 @@ inline void spmv_host(const Csr& A, const double* x, double* y) {
 inline void check_csr(const Csr& A, const char* what) {
   if ((int)A.rowptr.size() != A.rows + 1 || A.rowptr[0] != 0 || A.rowptr[A.rows] != A.nnz() ||
       A.vals.size() != A.colidx.size())
-    throw std::runtime_error(std::string("malformed CSR: ") + what);
+    throw ArgError(std::string("malformed CSR: ") + what);
   for (int r = 0; r < A.rows; ++r) {
-    if (A.rowptr[r + 1] < A.rowptr[r]) throw std::runtime_error(std::string("CSR rowptr not monotone: ") + what);
+    if (A.rowptr[r + 1] < A.rowptr[r]) throw ArgError(std::string("CSR rowptr not monotone: ") + what);
     for (int k = A.rowptr[r]; k < A.rowptr[r + 1]; ++k) {
-      if (A.colidx[k] < 0 || A.colidx[k] >= A.cols) throw std::runtime_error(std::string("CSR column out of range: ") + what);
-      if (k > A.rowptr[r] && A.colidx[k] <= A.colidx[k - 1]) throw std::runtime_error(std::string("CSR row not sorted/unique: ") + what);
+      if (A.colidx[k] < 0 || A.colidx[k] >= A.cols) throw ArgError(std::string("CSR column out of range: ") + what);
+      if (k > A.rowptr[r] && A.colidx[k] <= A.colidx[k - 1]) throw ArgError(std::string("CSR row not sorted/unique: ") + what);
     }
   }
 }

@@ -101,6 +101,20 @@ def test_parabolic_properties_2d_L6(M):
     assert all(b <= a + 1e-6 for a, b in zip(E, E[1:]))
 
 
+def test_parabolic_2d_L6_matches_oracle_golden(M):
+    """BASELINE config 5 at full size (2-D parabolic, L=6, h=0.1, t1=1, p=1 as in docs/src/guide.md:367): snapshots 1, 5
+    and 10 of the ten implicit-Euler steps against the CPU oracle's (tests/golden/make_golden_large.py)."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_parabolic_L6_p1_0.npz"))
+    sol = M.mpi_to_native(M.parabolic_solve(M.fem2d_mpi(6), h=0.1, t1=1.0, p=1.0))
+    assert np.allclose(sol.ts, gold["ts"], rtol=0, atol=1e-15) and len(sol.u) == 11
+    for k in gold["keep"]:
+        uk, rk = sol.u[int(k)], gold["u_%d" % int(k)]
+        print("parabolic L=6 snapshot %d: u rel l2 %.3e, all columns %.3e" % (k, rel(uk[:, 0], rk[:, 0]), rel(uk, rk)))
+        assert rel(uk[:, 0], rk[:, 0]) < 1e-10          # u at the reference's bar (test/test_parabolic.jl:93-104)
+        assert rel(uk, rk) < 1e-8                       # slack columns: flat directions, O(cond * eps)
+
+
 @pytest.mark.parametrize("kind,L,p", [("fem1d", 3, 1.0), ("fem2d", 3, 1.0), ("fem2d", 2, 2.0)])
 def test_feasibility_phase(M, kind, L, p):
     """SOL_feasibility (src:428-455): an infeasible start (slack too small) is repaired by the feasibility

@@ -282,3 +282,41 @@ def test_hpc_sparse_on_wire_layout():
         assert sum(b["nrows_local"] for b in blocks) == m
         assert all(np.all(np.diff(b["col_indices"]) > 0) for b in blocks)
         assert abs(M.hpc_from_local_blocks(blocks) - S).max() == 0
+
+
+def test_reduction_scratch_covers_global_unknowns_on_many_ranks(lib):
+    """the dots of a sharded solve run over the level's GLOBAL unknowns N (replicated), the objective
+    kernels over the LOCAL rows; the scratch must hold max(2 * blocks(n_local), blocks(N)).  256-thread blocks,
+    at most 2048 of them (csrc/kernels.hip: grid_for)."""
+    def blocks(m):
+        return max(1, min(2048, (m + 255) // 256))
+
+    out = C.c_longlong()
+    # fem2d L=7 at world 16 (n = 57 344, N = 49 154); parabolic (3 state variables, N ~ 1.3 n) at the 8-GPU target, L = 6..9
+    cases = [(57344 // 16, 49154), (57344 // 8, 49154)]
+    for L in (6, 7, 8, 9):
+        n = 14 * 4 ** (L - 1)
+        cases.append((n // 8, int(1.3 * n)))
+    for n_local, N in cases:
+        assert lib.mgb_reduction_scratch_doubles(n_local, N, C.byref(out)) == 0
+        assert out.value >= blocks(N), (n_local, N, out.value)              # launch_dot over the global unknowns
+        assert out.value >= 2 * blocks((n_local + 63) // 64 * 256), (n_local, N)   # fused objective: one block per 64 rows
+        assert out.value >= 2 * blocks(n_local)
+    assert lib.mgb_reduction_scratch_doubles(-1, 5, C.byref(out)) == -1
+
+
+def test_status_codes_come_from_exception_types(lib):
+    """capi.cpp: guard maps exception TYPES (csrc/errors.hpp) to MGB_E_* -- ARG for malformed input whatever the
+    message says, NUMERIC for a non-SPD matrix."""
+    h = C.c_void_p()
+    assert lib.mgb_fem3d_native(2, 7, C.byref(h)) == -1          # "fem3d: k must be 1, 2 or 3"
+    assert lib.mgb_fem3d_native(0, 3, C.byref(h)) == -1
+    assert lib.mgb_shard_rows(3, 2, 14, 7, C.byref(C.c_int()), C.byref(C.c_int())) == -1
+    x = np.zeros((2, 1)); w = np.ones(2)
+    dp = C.POINTER(C.c_double)
+    assert lib.mgb_geo_create(2, 1, 1, 1, x.ctypes.data_as(dp), w.ctypes.data_as(dp), C.byref(h)) == 0
+    rp = np.array([0, 2, 1], dtype=np.int32); ci = np.array([0, 1], dtype=np.int32); va = np.ones(2)
+    ip = C.POINTER(C.c_int32)
+    rc = lib.mgb_geo_set_matrix(h, b"op:id", 2, 2, rp.ctypes.data_as(ip), ci.ctypes.data_as(ip), va.ctypes.data_as(dp))
+    assert rc == -1 and b"CSR" in lib.mgb_last_error()
+    assert lib.mgb_geo_destroy(h) == 0
