@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- fem2d p-Laplace multigrid-barrier solve on MI355X (BASELINE.json metric).
 
-A "step" is one full `fem2d_mpi_solve`-equivalent main phase (amgb: t-continuation x level loop x
-Newton) on a geometry + AMG hierarchy already resident in HBM.  value = n * (Newton steps) * K /
-time  ("DoF/s per Newton step", BASELINE.md: DoF := n = rows of x, steps := sum(SOL_main.its)).
-N>1: one process per GPU (torch.distributed over RCCL).  Default: each rank solves its own replica of the
-workload (weak scaling, whole-job value); --shard: ONE solve row-block sharded over the ranks with RCCL
-allreduce of the gradient / Hessian values and a replicated factorisation (strong scaling).
+A "step" is one full `fem2d_mpi_solve`-equivalent main phase (amgb: t-continuation x level loop x Newton) on a
+geometry + AMG hierarchy already resident in HBM.  value = n * (Newton steps of the timed solves) / time
+("DoF/s per Newton step", BASELINE.md: DoF := n = rows of x, steps := sum(SOL_main.its)).  The reference's own
+benchmark times the whole `fem2d_mpi_solve` call including the hierarchy build (tools/benchmark_fem2d.jl:70-79), so
+the line also carries `setup_s` and `total_solve_s_incl_setup` = setup + one solve.
 
-One JSON line on rank 0.  Extra objects: `roofline` (dominant HIP kernel, HIP-event timed inside the
-solve on the library's own stream) and `cpu_baseline` (the numpy/scipy oracle timed on the host)."""
+N>1 (`--gpus N`): one process per GPU (torch.distributed over RCCL), launched by the driver through torchrun or -- when
+WORLD_SIZE is not set -- spawned from here before anything touches the GPU.  Default: ONE solve, row-block sharded over
+the ranks (BASELINE.json configs[2]: rows of x / Dz / the barrier kernels / the operators split by element blocks, the
+factorisation split by nested-dissection subtrees with a replicated top, RCCL allreduce for the exchanges; strong
+scaling).  `--replicas`: every rank solves its own copy (throughput mode, weak scaling).
+
+One JSON line on rank 0.  Extra objects: `roofline` (dominant HIP kernel, HIP-event timed inside the solve on the
+library's own stream), `cpu_baseline` (the same Newton path on the host cores), `parity` (z against the committed oracle
+vector of this workload, when there is one)."""
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,36 +32,77 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def cpu_baseline(L, p, budget_s):
-    """Oracle ('port'): Newton steps of the SAME schedule the GPU path runs (finest subspace, t = 0.1, 1, 10, ...),
-    on the same mesh, bounded to ~budget_s of host time."""
+    """The Newton path of this workload on the HOST cores (`kind = "port"`): the oracle's Newton / line-search loop
+    (oracle/mgb_oracle.py, numpy) on the same mesh with the same driver (oracle amgb_core: t-continuation, finest-level Newton), stopped at the budget, with the two
+    heavy pieces in C++ on all cores the process may use -- the Hessian values through the product's host plan
+    (T vec(Y), one thread) and `A \\ g` through the product's host multifrontal Cholesky (csrc/mfchol.cpp, the
+    `solver="host"` factorisation; worker threads from the affinity mask).  Bounded to ~budget_s of host time."""
+    import ctypes as C
     import numpy as np
+    import scipy.sparse as sp
     import mgb_oracle as O
-    # scipy.sparse products and SuperLU are single-threaded; pin the (few) dense BLAS calls to one thread too, so
-    # that `cores` is the number of threads the sample really used
-    import threadpoolctl
-    limiter = threadpoolctl.threadpool_limits(limits=1)
-    cores = 1
-    g = O.fem2d(L)
-    M = O.amg(g)
-    x = M.x
-    z = O.map_rows(lambda xi: O.DEFAULT_G[2](xi), x).reshape(-1, order="F")
-    c = O.map_rows(lambda xi: O.DEFAULT_F[2](xi), x)
-    B = O.Barrier(O.convex_Euclidian_power([1, 2, 3], p))
-    R = M.R[-1]
-    steps, t, t0 = 0, 0.1, time.time()
-    while time.time() - t0 < budget_s:
-        SOL = O.newton(lambda s, ref: B.f0_phi(s, x, M.w, t * c, R, M.D, z, ref),
-                       lambda s: B.f1(s, x, M.w, t * c, R, M.D, z), lambda s: B.f2(s, x, M.w, t * c, R, M.D, z),
-                       np.zeros(R.shape[1]), 4, O.stopping_exact(0.1))
-        steps += SOL["k"]
-        z = z + R @ SOL["x"]
-        t *= 10.0
-    dt = time.time() - t0
-    limiter.restore_original_limits()
-    n = x.shape[0]
-    return dict(value=n * steps / dt, unit="DoF/s per Newton step", cores=int(cores), kind="port",
-                sample="oracle/mgb_oracle.py (numpy/scipy, SuperLU solves): %d finest-level Newton steps (<=4 per "
-                       "centering, t = 0.1, 1, 10, ...) on fem2d L=%d p=%g, %.1f s of host time" % (steps, L, p, dt))
+    import mgb_amd as M
+    from mgb_amd import _lib
+    h = C.c_void_p()
+    _lib.call("mgb_fem2d_native", int(L), None, 0, C.byref(h))
+    plan, chol = C.c_void_p(), C.c_void_p()
+    try:
+        g = M._native_from_handle(h, "fem2d", ("id", "dx", "dy"))
+        idx = (C.c_int * 2)(1, 2)
+        _lib.call("mgb_plan_create", h, 2, _lib.str_array(M.DEFAULT_STATE), 4, _lib.str_array(M.DEFAULT_D[2]), 2, idx, 3,
+                  int(L) - 1, C.byref(plan))
+        _lib.call("mgb_plan_hostchol_create", plan, 2, C.byref(chol))
+        nthreads = C.c_int()
+        _lib.call("mgb_hostchol_info", chol, None, C.byref(nthreads), None)
+        N, nnz = C.c_int(), C.c_int()
+        _lib.call("mgb_plan_sizes", plan, C.byref(N), C.byref(nnz), None, None)
+        Mo = O.amg(g)                                   # R, D in the C++ builder's dof numbering (the plan's)
+        x, w = Mo.x, Mo.w
+        n = x.shape[0]
+        z = O.map_rows(lambda xi: O.DEFAULT_G[2](xi), x).reshape(-1, order="F")
+        c = O.map_rows(lambda xi: O.DEFAULT_F[2](xi), x)
+        Q = O.convex_Euclidian_power([1, 2, 3], p)
+        B = O.Barrier(Q)
+        assert Mo.R[-1].shape[1] == N.value
+        act = [1, 2, 3]                                 # active D rows of the cone: (q_1, q_2, s); slots (a <= b) row-major
+        vals, nstep = np.empty(nnz.value), np.empty(N.value)
+
+        class HostBarrier(O.Barrier):               # f2 -> lower-triangle values of R'HR in the plan's pattern order
+            def f2(self, s, x_, w_, c_, R_, D_, z0, pre=None):
+                H = self.Q.F2(x_, self._Dz(s, R_, D_, z0, pre))
+                Y = np.stack([w_ * H[:, act[a], act[b]] for a in range(3) for b in range(a, 3)], axis=1)
+                _lib.call("mgb_plan_eval_host", plan, _lib.dptr(_lib.f64(Y)), _lib.dptr(vals))
+                return vals
+
+        def solve(Hvals, grad):
+            gg = _lib.f64(grad)
+            _lib.call("mgb_hostchol_factor_solve", chol, _lib.dptr(Hvals), _lib.dptr(gg), _lib.dptr(nstep))
+            return nstep.copy()
+
+        saved = O.solve
+        O.solve = solve
+        try:
+            # the oracle's own driver (t-continuation with its kappa rule, finest-level Newton, line search), stopped
+            # after the first centering that ends beyond the budget
+            t0 = time.time()
+            SOL = O.amgb_core(HostBarrier(Q), Mo, z, c, float(np.sqrt(np.finfo(np.float64).eps)),
+                              early_stop=lambda Dz0: time.time() - t0 > budget_s)
+            dt = time.time() - t0
+            steps = int(SOL["its"].sum())
+            t_reached = float(SOL["ts"][-1])
+        finally:
+            O.solve = saved
+        return dict(value=n * steps / dt, unit="DoF/s per Newton step", cores=int(nthreads.value), kind="port",
+                    sample="oracle Newton / line-search loop (numpy, 1 thread) with the Hessian plan and the host multifrontal "
+                           "Cholesky of the product in C++ (%d threads): the first %d Newton steps of the same solve (oracle amgb_core: "
+                           "finest-level schedule, t = 0.1 ... %.3g, stopped after the centering that passed the budget) on fem2d "
+                           "L=%d p=%g, %.1f s of host time" % (nthreads.value, steps, t_reached, L, p, dt))
+    finally:
+        if chol:
+            _lib.call("mgb_hostchol_destroy", chol)
+        if plan:
+            _lib.call("mgb_plan_destroy", plan)
+        _lib.call("mgb_geo_destroy", h)
 
 
 def max_over_ranks(elapsed, dist=None, device="cpu"):
@@ -68,11 +116,24 @@ def max_over_ranks(elapsed, dist=None, device="cpu"):
 
 
 def whole_job_value(n, newton_steps_per_rank, world, elapsed):
-    """Replicas: every rank runs the same workload, so the job processed world * n * steps DoF-steps."""
+    """Replicas: every rank runs the same workload, so the job processed world * n * steps DoF-steps.  A sharded job
+    (all ranks on ONE solve) passes world = 1."""
     return world * n * newton_steps_per_rank / elapsed
 
 
-def main():
+def spawn_ranks(ngpus, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (torchrun) BEFORE this
+    process touches the GPU, relay their output and exit with their code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
@@ -82,20 +143,28 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", type=int, default=0)
-    ap.add_argument("--shard", action="store_true",
-                    help="N>1: ONE solve row-block sharded over the ranks (RCCL allreduce of gradient / Hessian values, "
-                         "replicated factorisation; strong scaling) instead of one replica per rank")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N>1: one independent replica of the workload per rank (throughput mode, weak scaling) instead of "
+                         "ONE row-block sharded solve over all ranks (the default, BASELINE.json configs[2])")
+    ap.add_argument("--shard", action="store_true", help="(default for N>1; kept for compatibility)")
     ap.add_argument("--probe-L", type=int, default=9,
-                    help="after the timed region, HIP-event time the barrier / SpMV kernels back to back on this larger "
-                         "mesh (0 = skip): the size at which they leave the launch-latency regime")
+                    help="after the timed region, HIP-event time the barrier / SpMV kernels on this larger mesh with rotating "
+                         "buffers (0 = skip): the size at which they leave the launch-latency regime")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N>1 on a single-GPU box: every rank uses cuda:0 and torch.distributed runs on gloo (RCCL refuses "
                          "two ranks on one device); exercises the multi-rank control flow, not a measurement")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))      # nothing has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     import torch
     dist = None
     if world > 1:
@@ -114,11 +183,11 @@ def main():
         raise SystemExit("bench.py: no HIP device visible (the HIP path has no CPU fallback)")
     dev = local_rank if world > 1 else 0
     backend = M.backend_hip(dev)
-    sharded = bool(args.shard and world > 1)
+    sharded = bool(world > 1 and not args.replicas)
     if sharded:      # one solve over all ranks: row blocks + RCCL allreduce
         backend.set_comm(rank, world, M.torch_allreduce(dist, dev))
 
-    # ---- setup (untimed): geometry upload + AMG hierarchy resident in HBM
+    # ---- setup (reported, not in `value`): geometry build + upload, AMG hierarchy, factorisation structures
     t_setup = time.time()
     geo = M.fem2d_mpi(args.L, backend=backend)
     A = M.AMG(geo, p=args.p)
@@ -127,6 +196,7 @@ def main():
     c = np.vstack([M.DEFAULT_F[2](xi) for xi in x])
     A.set_c(c)
     A.prepare()                  # operators, Hessian plan, factorisation structures: setup, not solve
+    backend.synchronize()
     t_setup = time.time() - t_setup
     n = A.n
     NL = A.level_size(A.L - 1)[0]
@@ -161,6 +231,7 @@ def main():
     elapsed = max_over_ranks(elapsed, dist, "cpu" if args.rehearse_one_gpu else "cuda")
     if dist is not None:
         dist.barrier()
+    z_final = A.get_z()          # collective on a sharded context: every rank calls it
 
     newton_steps = int(sum(int(s["its"].sum()) for s in sols))
     # replicas: every rank solved its own copy; sharded: all ranks worked on ONE solve
@@ -180,18 +251,20 @@ def main():
         # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # runs of this same command, gfx950 FETCH_SIZE x2 correction applied); null for other workloads
         traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            if pmc.get("workload") == "fem2d L=%d p=%g" % (args.L, args.p):
-                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if pmc.get("workload") == "fem2d L=%d p=%g" % (args.L, args.p) and dom in pmc["kernels"]:
+                    traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+                    break
+            except Exception:
+                continue
         roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                         avg_launch_us=1e3 * kd["ms"] / max(kd["launches"], 1), launches_timed=kd["launches"],
                         algorithmic_bytes_per_launch=kd["bytes"] / max(kd["launches"], 1),
                         note="latency-bound at this size: every working set is L2/Infinity-Cache resident and the "
-                             "factorisation + solve is a dependent chain of 47 short launches (DESIGN.md sections 4b, 5)",
+                             "factorisation + solve is a dependent chain of short launches (DESIGN.md sections 4b, 5)",
                         all_kernels={k: dict(gbs=v["bytes"] / max(v["ms"], 1e-12) / 1e6,
                                              avg_us=1e3 * v["ms"] / max(v["launches"], 1), launches_timed=v["launches"],
                                              est_total_s=est[k] / 1e3 / args.steps)
@@ -204,20 +277,36 @@ def main():
             "config": {"workload": "fem2d p-Laplace L=%d p=%g (n=%d rows, N_L=%d Newton unknowns), amgb main phase, "
                                    "tol=sqrt(eps)" % (args.L, args.p, n, NL),
                        "parallelism": "single GPU" if world == 1 else
-                       ("row-block sharded x%d (RCCL allreduce of gradient + Hessian values, replicated factorisation)"
-                        % world if sharded else "replicas x%d (not sharded)" % world)},
-            "total_solve_s": elapsed / args.steps, "newton_steps_per_solve": newton_steps / args.steps,
+                       ("one solve, row-block sharded x%d (RCCL allreduce of gradient / Hessian values / separator Schur "
+                        "complements; factorisation split by nested-dissection subtrees, top replicated)" % world
+                        if sharded else "replicas x%d (independent solves, not sharded)" % world)},
+            "total_solve_s": elapsed / args.steps, "setup_s": t_setup,
+            "total_solve_s_incl_setup": t_setup + elapsed / args.steps,
+            "newton_steps_per_solve": newton_steps / args.steps,
             "linear_solver": "gpu multifrontal Cholesky (csrc/gpuchol.hip)",
             "linear_solve_s_per_solve": sum(s["time_factor"] for s in sols) / args.steps,
             "barrier_spmv_kernel_s_per_solve": sum(est[k] for k in kern if not k.startswith("chol_")) / 1e3 / args.steps,
-            "setup_s": t_setup, "t_final": float(last["ts"][-1]), "c_dot_Dz_final": float(last["c_dot_Dz"][-1]),
+            "t_final": float(last["ts"][-1]), "c_dot_Dz_final": float(last["c_dot_Dz"][-1]),
             "roofline": roofline,
         }
+        # parity of the timed result: z against the CPU oracle's committed vector for this workload (tests/golden, data only)
+        gold = os.path.join(ROOT, "tests", "golden", "large_fem2d_L%d_p%s.npz" % (args.L, str(args.p).replace(".", "_")))
+        if os.path.exists(gold):
+            gz = np.load(gold)
+            zo = gz["z"].reshape(-1, order="F")
+            relz = float(np.linalg.norm(z_final - zo) / np.linalg.norm(zo))
+            relc = float(abs(out["c_dot_Dz_final"] - gz["c_dot_Dz"][-1]) / abs(gz["c_dot_Dz"][-1]))
+            out["parity"] = {"z_rel_l2_vs_oracle": relz, "c_dot_Dz_rel_vs_oracle": relc, "tolerance": 1e-10,
+                             "oracle_newton_steps": int(gz["its"].sum()), "fixture": os.path.basename(gold)}
+            if not (relz < 1e-8 and relc < 1e-8):
+                print(json.dumps(out))
+                raise SystemExit("bench.py: the timed solve does not reproduce the oracle's z (rel l2 %.3e)" % relz)
         if sharded:
             out["allreduce"] = backend.comm_stats()
         if args.probe_L > 0 and world == 1:      # N=1 only, like the CPU baseline
-            # secondary evidence for the bandwidth-shaped kernels: same kernels, back-to-back
-            # launches, on the workload mesh (cache resident, launch bound) and on a mesh that exceeds L2
+            # secondary evidence for the bandwidth-shaped kernels: the same kernels on the
+            # workload mesh (cache resident, launch bound) and on a mesh whose rotating working set exceeds the 256 MiB
+            # Infinity Cache
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import spmv_roofline
             out["kernel_bandwidth_probe"] = [spmv_roofline.probe(L, args.p) for L in sorted({args.L, args.probe_L})]

@@ -164,10 +164,12 @@ int mgb_amg_sol_get(mgb_amg a, long long* its /* L x nt col-major */, double* ts
  * order = apply_D, barrier_f2, hessian_assemble, barrier_f1, restrict, barrier_f0,
  *         chol_front_start, chol_front_step, chol_backward_rect, chol_backward, chol_front_single */
 int mgb_amg_sol_kernels(mgb_amg a, double* ms11, double* bytes11, long long* launches11);
-/* per-kernel device timings (HIP events on the context stream), ms and algorithmic bytes per launch:
+/* per-kernel device timings (HIP events on the context stream around `reps` back-to-back launches, rotating over `nrot`
+ * distinct copies of every operand so that a working set of nrot x bytes beyond the 256 MiB Infinity Cache is read from
+ * HBM), ms and algorithmic bytes per launch:
  * order = apply_D, barrier_f2, hessian_assemble, barrier_f1, restrict, barrier_f0, trial_f0 (the fused trial point +
  * apply_D + barrier_f0 launch every objective evaluation of the solve uses) */
-int mgb_amg_time_kernels(mgb_amg a, int level, int reps, double* ms7, double* bytes7);
+int mgb_amg_time_kernels(mgb_amg a, int level, int reps, int nrot, double* ms7, double* bytes7);
 
 /* ---- host-only symbolic helpers (no GPU needed; used by the CPU test-suite) ----------------- */
 typedef struct mgb_plan_s* mgb_plan;  /* symbolic products of one level: R, B=D*R, B', Hessian plan T */
@@ -191,6 +193,23 @@ int mgb_plan_apply_B_host(mgb_plan p, const double* s /* N */, double* Bs /* n_l
 int mgb_plan_apply_BT_host(mgb_plan p, const double* v /* n_local K */, double* g /* N */);
 int mgb_plan_chol_bench(mgb_plan p, const double* Y, int dim, int reps, double* seconds_per_factor,
                         double* seconds_per_solve, double* flops, double* front_doubles, double* residual);
+/* host-only: the product's HOST multifrontal Cholesky (csrc/mfchol.cpp, what solver="host" factors with; worker threads
+ * from the affinity mask) on this level's pattern, without a GPU: analyse once, then x = A \ g per Newton matrix.
+ * bench.py's cpu_baseline times the Newton path on the host cores with it.  MGB_E_NUMERIC if a pivot is not positive. */
+typedef struct mgb_hostchol_s* mgb_hostchol;
+int mgb_plan_hostchol_create(mgb_plan p, int dim, mgb_hostchol* out);
+int mgb_hostchol_destroy(mgb_hostchol c);
+int mgb_hostchol_info(mgb_hostchol c, int* n, int* threads, double* flops);
+int mgb_hostchol_factor_solve(mgb_hostchol c, const double* lower_vals, const double* g, double* x);
+/* The factorisation split over the ranks of a sharded job (the reference's MUMPS is distributed over its MPI ranks,
+ * README.md:23, tools/profile_ops.jl:117-126): the `world` subtrees log2(world) levels below the root of the elimination
+ * tree go to one rank each, the separators above them are factored redundantly from the subtree roots' Schur complements.
+ * partition: *split_world = ranks really used (1 = tree not splittable, everything replicated), owner[t] = rank of tree
+ * node t (postorder, as mgb_plan_chol_tree), -1 = top.  factor_solve_dist: the host mirror of the device scheme; `fn`
+ * sum-allreduces HOST doubles in place here.  Every rank passes the same values and right-hand side and gets all of x. */
+int mgb_hostchol_partition(mgb_hostchol c, int world, int* split_world, int cap, int* nnodes, int* owner);
+int mgb_hostchol_factor_solve_dist(mgb_hostchol c, int rank, int world, mgb_allreduce_fn fn, void* user,
+                                   const double* lower_vals, const double* g, double* x);
 /* host-only: the nested-dissection elimination tree of this level's pattern in postorder (children first):
  * own size, front size and parent (-1 = root) of the first min(cap, *nnodes) nodes */
 int mgb_plan_chol_tree(mgb_plan p, int dim, int cap, int* nnodes, int* ns, int* nf, int* parent);

@@ -754,10 +754,12 @@ class AMG:
     KERNEL_NAMES = ("apply_D", "barrier_f2", "hessian_assemble", "barrier_f1", "restrict", "barrier_f0",
                     "chol_front_start", "chol_front_step", "chol_backward_rect", "chol_backward", "chol_front_single")
 
-    def time_kernels(self, l, reps=50):
+    def time_kernels(self, l, reps=50, nrot=1):
+        """Back-to-back launches of each kernel class; nrot > 1 rotates over that many distinct copies of every operand
+        (working set nrot x bytes: beyond 256 MiB the rate is an HBM rate, not an Infinity-Cache rate)."""
         ms = np.empty(7)
         by = np.empty(7)
-        call("mgb_amg_time_kernels", self.handle, l, reps, dptr(ms), dptr(by))
+        call("mgb_amg_time_kernels", self.handle, l, reps, int(nrot), dptr(ms), dptr(by))
         names = ("apply_D", "barrier_f2", "hessian_assemble", "barrier_f1", "restrict", "barrier_f0", "trial_f0")
         return {k: dict(ms=float(m), bytes=float(b)) for k, m, b in zip(names, ms, by)}
 

@@ -94,7 +94,7 @@ PROTOTYPES = {
     "mgb_amg_sol_info": [H, c_int_p, c_dbl_p, c_dbl_p, c_ll_p],
     "mgb_amg_sol_get": [H, c_ll_p, c_dbl_p, c_dbl_p],
     "mgb_amg_sol_kernels": [H, c_dbl_p, c_dbl_p, c_ll_p],
-    "mgb_amg_time_kernels": [H, C.c_int, C.c_int, c_dbl_p, c_dbl_p],
+    "mgb_amg_time_kernels": [H, C.c_int, C.c_int, C.c_int, c_dbl_p, c_dbl_p],
     "mgb_plan_create": [H, C.c_int, c_str_arr, C.c_int, c_str_arr, C.c_int, c_int_p, C.c_int, C.c_int,
                         C.POINTER(H)],
     "mgb_reduction_scratch_doubles": [C.c_int, C.c_int, c_ll_p],
@@ -106,6 +106,12 @@ PROTOTYPES = {
     "mgb_plan_apply_B_host": [H, c_dbl_p, c_dbl_p],
     "mgb_plan_apply_BT_host": [H, c_dbl_p, c_dbl_p],
     "mgb_plan_chol_bench": [H, c_dbl_p, C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p],
+    "mgb_plan_hostchol_create": [H, C.c_int, C.POINTER(H)],
+    "mgb_hostchol_destroy": [H],
+    "mgb_hostchol_info": [H, c_int_p, c_int_p, c_dbl_p],
+    "mgb_hostchol_factor_solve": [H, c_dbl_p, c_dbl_p, c_dbl_p],
+    "mgb_hostchol_partition": [H, C.c_int, c_int_p, C.c_int, c_int_p, c_int_p],
+    "mgb_hostchol_factor_solve_dist": [H, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p, c_dbl_p, c_dbl_p, c_dbl_p],
     "mgb_plan_chol_tree": [H, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p],
     "mgb_chol_selftest": [C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],
 }

@@ -960,43 +960,95 @@ bool Amg::solve_host(int l, const double* avals, const double* g, double* nstep)
   return true;
 }
 
-Amg::KernelTimes Amg::time_kernels(int l, int reps) {
+// Back-to-back launches of one kernel, HIP-event timed on the context stream.  nrot > 1 rotates every launch over nrot
+// DISTINCT copies of all its operands (matrices and vectors), so that consecutive launches never touch the same bytes:
+// with nrot x (bytes per launch) beyond the 256 MiB Infinity Cache the figure is an HBM rate, not a cache-hit rate
+// (FETCH_SIZE counts Infinity-Cache hits too, MI355X_MICROARCH.md).
+Amg::KernelTimes Amg::time_kernels(int l, int reps, int nrot) {
   Level& lv = level(l);
   KernelTimes kt{};
+  if (nrot < 1) nrot = 1;
   hipEvent_t e0, e1;
   hip_check(hipEventCreate(&e0), "event");
   hip_check(hipEventCreate(&e1), "event");
   hip_check(hipMemsetAsync(lv.s.p, 0, (size_t)lv.plan.N * sizeof(double), ctx_.stream), "memset");
+  const int N = lv.plan.N, K = P_.K, nY = P_.nY(), nnzA = lv.plan.Apat.nnz();
+  // operand sets: set 0 = the level's own buffers, sets 1.. = copies
+  struct Set {
+    DevCsrOwned B, BT, T;
+    DevBuf<double> s, s2, dz0, dz, dzA, v, Y, g, avals, w, c, phi, phi2, partials, scal;
+  };
+  std::vector<std::unique_ptr<Set>> sets;
+  for (int r = 1; r < nrot; ++r) {
+    auto q = std::make_unique<Set>();
+    q->B.upload(lv.plan.B);
+    q->BT.upload(lv.plan.BT);
+    q->T.upload(lv.plan.T);
+    auto dup = [&](DevBuf<double>& dst, const double* src, size_t cnt) {
+      dst.alloc(cnt);
+      if (cnt) hip_check(hipMemcpyAsync(dst.p, src, cnt * sizeof(double), hipMemcpyDeviceToDevice, ctx_.stream), "dup");
+    };
+    dup(q->s, lv.s.p, N);
+    dup(q->s2, lv.s.p, N);
+    dup(q->dz0, Dz0_.p, (size_t)n_ * K);
+    dup(q->dz, Dz0_.p, (size_t)n_ * K);
+    dup(q->dzA, Dz0_.p, (size_t)n_ * K);
+    dup(q->v, Dz0_.p, (size_t)n_ * K);
+    q->Y.alloc((size_t)n_ * nY);
+    q->g.alloc(N);
+    q->avals.alloc(nnzA);
+    dup(q->w, w_.p, n_);
+    dup(q->c, c_.p, (size_t)n_ * K);
+    q->phi.alloc((size_t)n_ * P_.ncones);
+    hip_check(hipMemsetAsync(q->phi.p, 0, q->phi.n * sizeof(double), ctx_.stream), "memset phi");
+    q->phi2.alloc((size_t)n_ * P_.ncones);
+    q->partials.alloc(partials_.n);
+    q->scal.alloc(8);
+    sets.push_back(std::move(q));
+  }
+  struct View {
+    DevCsr B, BT, T;
+    double *s, *s2, *dz0, *dz, *dzA, *v, *Y, *g, *avals, *w, *c, *phi, *phi2, *partials, *scal;
+  };
+  std::vector<View> vw;
+  vw.push_back(View{lv.B.view, lv.BT.view, lv.T.view, lv.s.p, lv.s_trial.p, Dz0_.p, Dz_.p, DzA_.p, v_.p, Y_.p, lv.g.p,
+                    lv.avals.p, w_.p, c_.p, phi_cur_.p, phi_trial_.p, partials_.p, scal_.p});
+  for (auto& q : sets)
+    vw.push_back(View{q->B.view, q->BT.view, q->T.view, q->s.p, q->s2.p, q->dz0.p, q->dz.p, q->dzA.p, q->v.p, q->Y.p, q->g.p,
+                      q->avals.p, q->w.p, q->c.p, q->phi.p, q->phi2.p, q->partials.p, q->scal.p});
   auto timeit = [&](auto&& fn) {
-    fn();  // warm
+    for (int r = 0; r < nrot; ++r) fn(vw[r]);  // warm (code objects, first touch)
     hip_check(hipEventRecord(e0, ctx_.stream), "rec");
-    for (int r = 0; r < reps; ++r) fn();
+    for (int r = 0; r < reps; ++r) fn(vw[r % nrot]);
     hip_check(hipEventRecord(e1, ctx_.stream), "rec");
     hip_check(hipEventSynchronize(e1), "evsync");
     float ms = 0;
     hip_check(hipEventElapsedTime(&ms, e0, e1), "elapsed");
     return (double)ms / reps;
   };
-  const double n = n_, K = P_.K, nY = P_.nY();
-  kt.apply_ms = timeit([&] { dev_apply(lv, lv.s.p, Dz_.p); });
+  const double n = n_;
+  // the Dz every barrier kernel reads must be a feasible point: Dz = Dz0 + B*0
+  for (auto& V : vw) launch_spmv(ctx_.stream, V.B, V.s, V.dz0, V.dz);
+  kt.apply_ms = timeit([&](View& V) { launch_spmv(ctx_.stream, V.B, V.s, V.dz0, V.dz); });
   kt.apply_bytes = csr_bytes(lv.B.view, true);
-  kt.f2_ms = timeit([&] { launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p); });
+  kt.f2_ms = timeit([&](View& V) { launch_barrier_f2(ctx_.stream, n_, P_, V.dz, V.w, V.Y); });
   kt.f2_bytes = n * (K + 1 + nY) * 8;
-  kt.assemble_ms = timeit([&] { launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p); });
+  kt.assemble_ms = timeit([&](View& V) { launch_spmv(ctx_.stream, V.T, V.Y, nullptr, V.avals); });
   kt.assemble_bytes = csr_bytes(lv.T.view, false);
-  kt.f1_ms = timeit([&] { launch_barrier_f1(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, 1.0, v_.p); });
+  kt.f1_ms = timeit([&](View& V) { launch_barrier_f1(ctx_.stream, n_, P_, V.dz, V.w, V.c, 1.0, V.v); });
   kt.f1_bytes = n * (3 * K + 1) * 8;
-  kt.restrict_ms = timeit([&] { launch_spmv(ctx_.stream, lv.BT.view, v_.p, nullptr, lv.g.p); });
+  kt.restrict_ms = timeit([&](View& V) { launch_spmv(ctx_.stream, V.BT, V.v, nullptr, V.g); });
   kt.restrict_bytes = csr_bytes(lv.BT.view, false);
-  kt.f0_ms = timeit([&] {
-    launch_barrier_f0(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, phi_cur_.p, 0.0, phi_trial_.p, partials_.p, scal_.p);
+  kt.f0_ms = timeit([&](View& V) {
+    launch_barrier_f0(ctx_.stream, n_, P_, V.dz, V.w, V.c, V.phi, 0.0, V.phi2, V.partials, V.scal);
   });
   kt.f0_bytes = n * (2 * K + 3) * 8;
-  kt.trial_ms = timeit([&] {      // the fused objective evaluation the solve actually runs
-    launch_trial_f0(ctx_.stream, lv.B.view, n_, P_, lv.s.p, -0.5, lv.s.p, lv.s_trial.p, Dz0_.p, DzA_.p, w_.p, c_.p,
-                    phi_cur_.p, 0.0, phi_trial_.p, partials_.p, scal_.p);
+  kt.trial_ms = timeit([&](View& V) {      // the fused objective evaluation the solve runs on launch-bound meshes
+    launch_trial_f0(ctx_.stream, V.B, n_, P_, V.s, -0.5, V.s, V.s2, V.dz0, V.dzA, V.w, V.c, V.phi, 0.0, V.phi2, V.partials,
+                    V.scal);
   });
   kt.trial_bytes = trial_bytes(lv, true);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return kt;

@@ -229,7 +229,7 @@ class Amg {
     double apply_ms, f2_ms, assemble_ms, f1_ms, restrict_ms, f0_ms, trial_ms;
     double apply_bytes, f2_bytes, assemble_bytes, f1_bytes, restrict_bytes, f0_bytes, trial_bytes;
   };
-  KernelTimes time_kernels(int l, int reps);
+  KernelTimes time_kernels(int l, int reps, int nrot = 1);      // nrot: rotate over this many distinct copies of every operand
 
  private:
   struct Level {

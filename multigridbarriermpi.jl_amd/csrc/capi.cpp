@@ -38,6 +38,9 @@ struct mgb_plan_s {
   LevelPlan plan;
   int n, nY;
 };
+struct mgb_hostchol_s {
+  MfChol ch;
+};
 
 namespace {
 
@@ -755,10 +758,10 @@ int mgb_amg_sol_kernels(mgb_amg a, double* ms11, double* bytes11, long long* lau
     }
   });
 }
-int mgb_amg_time_kernels(mgb_amg a, int level, int reps, double* ms7, double* bytes7) {
+int mgb_amg_time_kernels(mgb_amg a, int level, int reps, int nrot, double* ms7, double* bytes7) {
   return guard([&] {
-    need(a && ms7 && bytes7 && reps > 0 && level >= 0 && level < a->amg->L(), "time_kernels: bad arguments");
-    Amg::KernelTimes k = a->amg->time_kernels(level, reps);
+    need(a && ms7 && bytes7 && reps > 0 && nrot >= 1 && nrot <= 64 && level >= 0 && level < a->amg->L(), "time_kernels: bad arguments");
+    Amg::KernelTimes k = a->amg->time_kernels(level, reps, nrot);
     const double ms[7] = {k.apply_ms, k.f2_ms, k.assemble_ms, k.f1_ms, k.restrict_ms, k.f0_ms, k.trial_ms};
     const double by[7] = {k.apply_bytes, k.f2_bytes, k.assemble_bytes, k.f1_bytes, k.restrict_bytes, k.f0_bytes, k.trial_bytes};
     std::copy(ms, ms + 7, ms7);
@@ -886,6 +889,62 @@ int mgb_plan_chol_bench(mgb_plan p, const double* Y, int dim, int reps, double* 
     if (flops) *flops = ch.factor_flops();
     if (front_doubles) *front_doubles = (double)ch.front_doubles();
     if (residual) *residual = mx / sc;
+  });
+}
+
+int mgb_plan_hostchol_create(mgb_plan p, int dim, mgb_hostchol* out) {
+  return guard([&] {
+    need(p && out && dim >= 1 && dim <= 3, "hostchol_create: bad arguments");
+    auto* c = new mgb_hostchol_s;
+    try {
+      c->ch.analyze(p->plan.Apat, p->plan.coords.data(), dim);
+    } catch (...) {
+      delete c;
+      throw;
+    }
+    *out = c;
+  });
+}
+int mgb_hostchol_destroy(mgb_hostchol c) {
+  return guard([&] { delete c; });
+}
+int mgb_hostchol_info(mgb_hostchol c, int* n, int* threads, double* flops) {
+  return guard([&] {
+    need(c, "null argument");
+    if (n) *n = c->ch.size();
+    if (threads) *threads = MfChol::threads();
+    if (flops) *flops = c->ch.factor_flops();
+  });
+}
+int mgb_hostchol_factor_solve(mgb_hostchol c, const double* lower_vals, const double* g, double* x) {
+  return guard([&] {
+    need(c && lower_vals && g && x, "hostchol_factor_solve: null argument");
+    if (!c->ch.factor(lower_vals)) throw NumericError("MfChol: matrix is not positive definite");
+    if (x != g) std::copy(g, g + c->ch.size(), x);
+    c->ch.solve(x);
+  });
+}
+
+int mgb_hostchol_partition(mgb_hostchol c, int world, int* split_world, int cap, int* nnodes, int* owner) {
+  return guard([&] {
+    need(c && world >= 1, "hostchol_partition: bad arguments");
+    CholPartition part = c->ch.partition(world);
+    if (split_world) *split_world = part.world;
+    if (nnodes) *nnodes = (int)part.owner.size();
+    if (owner) std::copy(part.owner.begin(), part.owner.begin() + std::min<size_t>(cap, part.owner.size()), owner);
+  });
+}
+int mgb_hostchol_factor_solve_dist(mgb_hostchol c, int rank, int world, mgb_allreduce_fn fn, void* user, const double* lower_vals,
+                                   const double* g, double* x) {
+  return guard([&] {
+    need(c && lower_vals && g && x && world >= 1 && rank >= 0 && rank < world && (world == 1 || fn), "hostchol_factor_solve_dist: bad arguments");
+    CholPartition part = c->ch.partition(world);
+    if (x != g) std::copy(g, g + c->ch.size(), x);
+    auto ar = [&](double* ptr, long long count) {
+      const int rc = fn(user, ptr, count);
+      if (rc != 0) throw InternalError("mgb: allreduce callback failed with code " + std::to_string(rc));
+    };
+    if (!c->ch.factor_solve_dist(lower_vals, x, part, rank, ar)) throw NumericError("MfChol: matrix is not positive definite");
   });
 }
 

@@ -220,6 +220,8 @@ bool partial_chol(double* F, int nf, int ns, int nthreads) {
 
 }  // namespace
 
+int MfChol::threads() { return hw_threads(); }
+
 int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const double* coords, int dim, int leaf,
                   std::vector<int>& label, int& next_label, std::vector<std::vector<int>>& own) {
   const int cnt = hi - lo;
@@ -491,39 +493,140 @@ bool MfChol::factor(const double* vals) {
   return ok;
 }
 
+void MfChol::forward_node(int t, double* y) const {      // L y = b restricted to the pivots of node t
+  const Node& nd = nodes_[t];
+  const int nf = nd.nf(), ns = nd.ns;
+  const double* F = fronts_.data() + nd.off;
+  double* yo = y + nd.first;
+  for (int k = 0; k < ns; ++k) {
+    const double* ck = F + (size_t)k * nf;
+    const double v = yo[k] / ck[k];
+    yo[k] = v;
+    for (int i = k + 1; i < ns; ++i) yo[i] -= ck[i] * v;
+    for (int i = ns; i < nf; ++i) y[nd.bdry[i - ns]] -= ck[i] * v;
+  }
+}
+
+void MfChol::backward_node(int t, double* y) const {     // L' x = y restricted to the pivots of node t
+  const Node& nd = nodes_[t];
+  const int nf = nd.nf(), ns = nd.ns;
+  const double* F = fronts_.data() + nd.off;
+  double* yo = y + nd.first;
+  for (int k = ns - 1; k >= 0; --k) {
+    const double* ck = F + (size_t)k * nf;
+    double v = yo[k];
+    for (int i = k + 1; i < ns; ++i) v -= ck[i] * yo[i];
+    for (int i = ns; i < nf; ++i) v -= ck[i] * y[nd.bdry[i - ns]];
+    yo[k] = v / ck[k];
+  }
+}
+
 void MfChol::solve(double* b) const {
   if (n_ == 0) return;
   std::vector<double> y(n_);
   for (int i = 0; i < n_; ++i) y[i] = b[perm_[i]];
-  std::vector<double> tmp;
   const int nn = (int)nodes_.size();
-  for (int t = 0; t < nn; ++t) {  // forward: L y = b
-    const Node& nd = nodes_[t];
-    const int nf = nd.nf(), ns = nd.ns;
-    const double* F = fronts_.data() + nd.off;
-    double* yo = y.data() + nd.first;
-    for (int k = 0; k < ns; ++k) {
-      const double* ck = F + (size_t)k * nf;
-      const double v = yo[k] / ck[k];
-      yo[k] = v;
-      for (int i = k + 1; i < ns; ++i) yo[i] -= ck[i] * v;
-      for (int i = ns; i < nf; ++i) y[nd.bdry[i - ns]] -= ck[i] * v;
-    }
-  }
-  for (int t = nn - 1; t >= 0; --t) {  // backward: L' x = y
-    const Node& nd = nodes_[t];
-    const int nf = nd.nf(), ns = nd.ns;
-    const double* F = fronts_.data() + nd.off;
-    double* yo = y.data() + nd.first;
-    for (int k = ns - 1; k >= 0; --k) {
-      const double* ck = F + (size_t)k * nf;
-      double v = yo[k];
-      for (int i = k + 1; i < ns; ++i) v -= ck[i] * yo[i];
-      for (int i = ns; i < nf; ++i) v -= ck[i] * y[nd.bdry[i - ns]];
-      yo[k] = v / ck[k];
-    }
-  }
+  for (int t = 0; t < nn; ++t) forward_node(t, y.data());
+  for (int t = nn - 1; t >= 0; --t) backward_node(t, y.data());
   for (int i = 0; i < n_; ++i) b[perm_[i]] = y[i];
+}
+
+CholPartition MfChol::partition(int world) const {
+  CholPartition part;
+  const int nn = (int)nodes_.size();
+  part.owner.assign(nn, -1);
+  if (world < 2 || (world & (world - 1)) || roots_.size() != 1) return part;      // replicated
+  std::vector<int> frontier{roots_[0]};
+  for (int w = 1; w < world; w *= 2) {
+    std::vector<int> next;
+    for (int t : frontier) {
+      if (nodes_[t].children.size() != 2) return part;      // top is not a complete binary tree: replicate
+      next.push_back(nodes_[t].children[0]);
+      next.push_back(nodes_[t].children[1]);
+    }
+    frontier.swap(next);
+  }
+  // postorder: the subtree of t is the contiguous node range [t - size(t) + 1, t]
+  std::vector<int> sz(nn, 1);
+  for (int t = 0; t < nn; ++t)
+    if (nodes_[t].parent >= 0) sz[nodes_[t].parent] += sz[t];
+  for (int j = 0; j < world; ++j) {
+    const int r = frontier[j];
+    if (nodes_[r].bdry.empty() && nodes_[r].parent >= 0) {}      // a subtree without boundary exchanges nothing: fine
+    for (int t = r - sz[r] + 1; t <= r; ++t) part.owner[t] = j;
+  }
+  part.world = world;
+  part.roots = frontier;
+  return part;
+}
+
+bool MfChol::factor_solve_dist(const double* vals, double* b, const CholPartition& part, int rank, const Allreduce& allreduce) {
+  if (n_ == 0) return true;
+  const int nn = (int)nodes_.size();
+  if (!part.split()) {
+    const bool ok = factor(vals);
+    if (ok) solve(b);
+    return ok;
+  }
+  if ((int)part.owner.size() != nn || rank < 0 || rank >= part.world) throw ArgError("MfChol: partition does not match the tree");
+  bool ok = true;
+  std::vector<double> y(n_), y0(n_);
+  for (int i = 0; i < n_; ++i) y0[i] = y[i] = b[perm_[i]];
+  // (1) own subtree: factor, forward sweep (its updates of top unknowns are the right-hand-side contribution)
+  for (int t = 0; t < nn; ++t)
+    if (part.owner[t] == rank) factor_node(t, vals, ok);
+  for (int t = 0; t < nn && ok; ++t)
+    if (part.owner[t] == rank) forward_node(t, y.data());
+  // (2) exchange: [flag | per subtree root: lower triangle of its Schur complement | updates of the top right-hand side]
+  std::vector<int> top_dofs;
+  for (int t = 0; t < nn; ++t)
+    if (part.owner[t] < 0)
+      for (int k = 0; k < nodes_[t].ns; ++k) top_dofs.push_back(nodes_[t].first + k);
+  std::vector<long long> xoff(part.world + 1, 1);
+  for (int j = 0; j < part.world; ++j) {
+    const long long nb = (long long)nodes_[part.roots[j]].bdry.size();
+    xoff[j + 1] = xoff[j] + nb * (nb + 1) / 2;
+  }
+  std::vector<double> xb((size_t)xoff[part.world] + top_dofs.size(), 0.0);
+  xb[0] = ok ? 0.0 : 1.0;
+  if (ok) {
+    const Node& ch = nodes_[part.roots[rank]];
+    const int cf = ch.nf(), cs = ch.ns, nb = (int)ch.bdry.size();
+    const double* G = fronts_.data() + ch.off;
+    double* dst = xb.data() + xoff[rank];
+    for (int bcol = 0; bcol < nb; ++bcol)
+      for (int a = bcol; a < nb; ++a) *dst++ = G[(size_t)(cs + bcol) * cf + cs + a];
+    for (size_t q = 0; q < top_dofs.size(); ++q) xb[(size_t)xoff[part.world] + q] = y[top_dofs[q]] - y0[top_dofs[q]];
+  }
+  allreduce(xb.data(), (long long)xb.size());
+  if (xb[0] != 0.0) return false;      // some rank hit a non-positive pivot
+  for (int j = 0; j < part.world; ++j) {
+    Node& ch = nodes_[part.roots[j]];
+    const int cf = ch.nf(), cs = ch.ns, nb = (int)ch.bdry.size();
+    double* G = fronts_.data() + ch.off;
+    const double* src = xb.data() + xoff[j];
+    for (int bcol = 0; bcol < nb; ++bcol)
+      for (int a = bcol; a < nb; ++a) G[(size_t)(cs + bcol) * cf + cs + a] = *src++;
+  }
+  for (size_t q = 0; q < top_dofs.size(); ++q) y[top_dofs[q]] = y0[top_dofs[q]] + xb[(size_t)xoff[part.world] + q];
+  // (3) top: every rank does the same arithmetic on the same data
+  for (int t = 0; t < nn; ++t)
+    if (part.owner[t] < 0) factor_node(t, vals, ok);
+  if (!ok) return false;      // identical on every rank
+  for (int t = 0; t < nn; ++t)
+    if (part.owner[t] < 0) forward_node(t, y.data());
+  for (int t = nn - 1; t >= 0; --t)
+    if (part.owner[t] < 0) backward_node(t, y.data());
+  // (4) own subtree back, then assemble x: every unknown is contributed by exactly one rank (the top by rank 0)
+  for (int t = nn - 1; t >= 0; --t)
+    if (part.owner[t] == rank) backward_node(t, y.data());
+  std::vector<double> xs(n_, 0.0);
+  for (int t = 0; t < nn; ++t)
+    if (part.owner[t] == rank || (part.owner[t] < 0 && rank == 0))
+      for (int k = 0; k < nodes_[t].ns; ++k) xs[perm_[nodes_[t].first + k]] = y[nodes_[t].first + k];
+  allreduce(xs.data(), n_);
+  std::copy(xs.begin(), xs.end(), b);
+  return true;
 }
 
 }  // namespace mgb

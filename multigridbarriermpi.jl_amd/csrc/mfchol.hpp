@@ -9,11 +9,23 @@
 // the new values, runs dense partial factorizations up the tree (OpenMP tasks over subtrees) and
 // does the two triangular sweeps.
 #pragma once
+#include <functional>
 #include <vector>
 
 #include "sparse.hpp"
 
 namespace mgb {
+
+// Split of the elimination tree over the ranks of a row-block sharded job (the reference factors through MUMPS
+// distributed over its MPI ranks, README.md:23, tools/profile_ops.jl:117-126): the `world` subtrees hanging log2(world)
+// levels below the root go to one rank each; the separators above them (the "top") are factored redundantly by every
+// rank from the subtree roots' Schur complements, which are the only factorisation data that crosses ranks.
+struct CholPartition {
+  int world = 1;                 // ranks the factorisation is split over (1: every rank factors everything)
+  std::vector<int> owner;        // per tree node (postorder): owning rank, -1 = top (replicated)
+  std::vector<int> roots;        // the subtree roots, left to right (roots[j] belongs to rank j)
+  bool split() const { return world > 1; }
+};
 
 class MfChol {
  public:
@@ -25,7 +37,16 @@ class MfChol {
   bool factor(const double* vals);
   // in-place solve; b has N entries in the ORIGINAL ordering.
   void solve(double* b) const;
+  // in-place distributed solve of A x = b over `world` ranks (host mirror of GpuChol's scheme): this rank factors its
+  // subtree, the ranks exchange the subtree roots' Schur complements and right-hand-side updates through `allreduce`
+  // (sum over ranks, in place, of `count` doubles -- the only collective), every rank factors the top and finishes its
+  // own unknowns, and a second allreduce assembles x.  Returns false on a non-positive pivot on ANY rank.
+  typedef std::function<void(double*, long long)> Allreduce;
+  bool factor_solve_dist(const double* vals, double* b, const CholPartition& part, int rank, const Allreduce& allreduce);
+  // subtree split for `world` ranks (power of two, complete binary top); world = 1 in the result means "not splittable"
+  CholPartition partition(int world) const;
   int size() const { return n_; }
+  static int threads();      // worker threads factor() uses (affinity mask, capped at 16; MGB_NUM_THREADS overrides)
   size_t front_doubles() const { return fronts_.size(); }
   double factor_flops() const { return flops_; }
   int num_nodes() const { return (int)nodes_.size(); }
@@ -50,6 +71,8 @@ class MfChol {
   int build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const double* coords, int dim, int leaf,
             std::vector<int>& label, int& next_label, std::vector<std::vector<int>>& own);
   void factor_node(int t, const double* vals, bool& ok);
+  void forward_node(int t, double* y) const;
+  void backward_node(int t, double* y) const;
   int n_ = 0, max_front_ = 0;
   double flops_ = 0;
   std::vector<int> perm_, iperm_;       // perm_[new] = old ; iperm_[old] = new

@@ -213,3 +213,107 @@ def test_plan_shards_sum_to_the_full_plan_gloo_world3_uneven():
         assert blocks[0][0] == 0 and blocks[-1][1] == blocks[0][2]
         assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
         assert len({b[1] - b[0] for b in blocks}) > 1          # uneven
+
+
+# ---------------------------------------------------------------- distributed factorisation (subtrees -> ranks)
+def _chol_dist_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for pth in (ROOT, os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, pth)
+    import torch
+    import torch.distributed as dist
+    from mgb_amd import _lib
+    call, dptr, f64 = _lib.call, _lib.dptr, _lib.f64
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def thunk(_user, ptr, count):                       # sum-allreduce of HOST doubles in place (gloo)
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(count,))
+            t = torch.from_numpy(a)
+            dist.all_reduce(t)
+            calls.append(int(count))
+            return 0
+
+        cb = _lib.ALLREDUCE_FN(thunk)
+        out = {}
+        for kind, L in (("fem2d", 4), ("fem1d", 7)):
+            h, p, n, S, K, block, N, nz = _full_plan(kind, L, L - 1)
+            dim = 1 if kind == "fem1d" else 2
+            nY = (dim + 1) * (dim + 2) // 2
+            rng = np.random.default_rng(11)                  # same stream on every rank
+            # an SPD Newton matrix from the plan: Y = w-like positive diagonal slots, small off-diagonal ones
+            Y = np.zeros((n, nY))
+            slot = 0
+            for a in range(dim + 1):
+                for b in range(a, dim + 1):
+                    Y[:, slot] = (1.0 + rng.random(n)) if a == b else 0.1 * rng.standard_normal(n)
+                    slot += 1
+            vals = np.empty(nz)
+            call("mgb_plan_eval_host", p, dptr(f64(Y)), dptr(vals))
+            g = rng.standard_normal(N)
+            ch = C.c_void_p()
+            call("mgb_plan_hostchol_create", p, dim, C.byref(ch))
+            x_ref = np.empty(N)
+            call("mgb_hostchol_factor_solve", ch, dptr(vals), dptr(f64(g)), dptr(x_ref))
+            sw, nn = C.c_int(), C.c_int()
+            call("mgb_hostchol_partition", ch, world, C.byref(sw), 0, C.byref(nn), None)
+            owner = np.empty(nn.value, dtype=np.int32)
+            call("mgb_hostchol_partition", ch, world, C.byref(sw), nn.value, C.byref(nn), owner.ctypes.data_as(_lib.c_int_p))
+            x = np.empty(N)
+            n0 = len(calls)
+            call("mgb_hostchol_factor_solve_dist", ch, rank, world, cb, None, dptr(vals), dptr(f64(g)), dptr(x))
+            out[kind] = dict(split=sw.value, owner=owner, err=float(np.abs(x - x_ref).max() / np.abs(x_ref).max()),
+                             x=x, exchanges=calls[n0:])
+            # a non-SPD matrix on the subtree of ONE rank must fail on every rank (flag travels with the exchange)
+            bad = vals.copy()
+            rp = np.empty(N + 1, dtype=np.int32)
+            ci = np.empty(nz, dtype=np.int32)
+            call("mgb_plan_pattern", p, _lib.iptr(rp), _lib.iptr(ci))
+            diag = [k for r in range(N) for k in range(rp[r], rp[r + 1]) if ci[k] == r]
+            bad[diag[0]] = -1.0
+            rc = _lib.load().mgb_hostchol_factor_solve_dist(ch, rank, world, cb, None, dptr(bad), dptr(f64(g)), dptr(x.copy()))
+            out[kind]["bad_rc"] = rc
+            call("mgb_hostchol_destroy", ch)
+            call("mgb_plan_destroy", p)
+            call("mgb_geo_destroy", h)
+        q.put((rank, out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_distributed_factor_solve_host_gloo(world):
+    """The factorisation split by nested-dissection subtrees (one subtree per rank, replicated top, Schur complements and
+    right-hand-side updates of the subtree roots summed over the ranks -- the scheme csrc/gpuchol.hip runs on the GPUs)
+    through the C ABI on `world` gloo ranks: x equals the undistributed solve, the ranks agree bit for bit, exactly two
+    collectives per solve, and a non-SPD matrix is reported by every rank."""
+    out = _run(_chol_dist_worker, world)
+    for kind in out[0][1]:
+        rs = [o[1][kind] for o in out]
+        assert all(r["split"] == world for r in rs)
+        own = rs[0]["owner"]
+        assert set(own.tolist()) == set(range(-1, world))              # every rank owns a subtree, the top is replicated
+        assert own[-1] == -1                                           # the root (last in postorder) is top
+        for r in rs:
+            assert np.array_equal(r["owner"], own)
+            assert r["err"] < 1e-12
+            assert np.array_equal(r["x"], rs[0]["x"])
+            assert len(r["exchanges"]) == 2 and r["exchanges"] == rs[0]["exchanges"]
+            assert r["bad_rc"] == -3                                   # MGB_E_NUMERIC everywhere
+
+
+def test_partition_falls_back_to_replication(lib):
+    """world that is not a power of two, or larger than the tree can be split into: everything replicated (split = 1)."""
+    from mgb_amd import _lib
+    h, p, n, S, K, block, N, nz = _full_plan("fem2d", 2, 1)
+    ch = C.c_void_p()
+    _lib.call("mgb_plan_hostchol_create", p, 2, C.byref(ch))
+    for world in (1, 3, 6, 1024):
+        sw, nn = C.c_int(), C.c_int()
+        _lib.call("mgb_hostchol_partition", ch, world, C.byref(sw), 0, C.byref(nn), None)
+        assert sw.value == 1
+    _lib.call("mgb_hostchol_destroy", ch)
+    _lib.call("mgb_plan_destroy", p)
+    _lib.call("mgb_geo_destroy", h)

@@ -17,7 +17,13 @@ import mgb_amd as M         # noqa: E402
 HBM_PEAK_GBS = 8000.0
 
 
-def probe(L, p=1.0, reps=20):
+INFINITY_CACHE_BYTES = 256 * 2 ** 20
+
+
+def probe(L, p=1.0, reps=24, nrot=None):
+    """nrot (default: as many distinct operand copies as it takes for the smallest rotating working set -- the barrier
+    kernels' ~5 MB x L-dependent -- to exceed twice the 256 MiB Infinity Cache, capped at 8; 1 on cache-resident meshes
+    means "same buffers every launch", which is how the solve itself runs at L=7)."""
     t0 = time.time()
     geo = M.fem2d_mpi(L)
     A = M.AMG(geo, p=p)
@@ -27,11 +33,15 @@ def probe(L, p=1.0, reps=20):
     z0 = np.column_stack([x[:, 0] ** 2 + x[:, 1] ** 2, np.full(n, 100.0)]).reshape(-1, order="F")   # DEFAULT_G[2]
     A.set_c(c)
     A.set_z(z0)
-    kt = A.time_kernels(A.L - 1, reps)
-    out = dict(L=L, n=n, N=A.level_size(A.L - 1)[0], setup_s=time.time() - t0, kernels={})
+    if nrot is None:
+        smallest = n * (2 * 4 + 3) * 8            # barrier_f0, the smallest launch
+        nrot = 1 if L <= 7 else int(min(8, max(2, -(-2 * INFINITY_CACHE_BYTES // smallest))))
+    kt = A.time_kernels(A.L - 1, reps, nrot)
+    out = dict(L=L, n=n, N=A.level_size(A.L - 1)[0], setup_s=time.time() - t0, rotating_copies=nrot, kernels={})
     for k, v in kt.items():
         gbs = v["bytes"] / max(v["ms"], 1e-9) / 1e6
-        out["kernels"][k] = dict(us=1e3 * v["ms"], MB=v["bytes"] / 1e6, GBs=gbs, frac_hbm=gbs / HBM_PEAK_GBS)
+        out["kernels"][k] = dict(us=1e3 * v["ms"], MB=v["bytes"] / 1e6, GBs=gbs, frac_hbm=gbs / HBM_PEAK_GBS,
+                                 rotating_working_set_MB=nrot * v["bytes"] / 1e6)
     return out
 
 
