@@ -129,6 +129,10 @@ int mgb_amg_local_rows(mgb_amg a, int* n_global, int* row0, int* n_local);
  * mgb_amg_solve is pure compute */
 int mgb_amg_prepare(mgb_amg a, int level);
 int mgb_amg_level_size(mgb_amg a, int level, int* N, int* nnz_lower);
+/* device factorisation of `level` (built now if needed): *split_world = ranks it is split over by nested-dissection subtrees
+ * on a sharded context (1 = replicated: single GPU, or a world the tree cannot be split into), doubles exchanged per Newton
+ * system (subtree-root Schur complements + the assembled solution), kernel launches per Newton system */
+int mgb_amg_chol_info(mgb_amg a, int level, int* split_world, double* exchange_doubles, int* launches);
 int mgb_amg_hessian_pattern(mgb_amg a, int level, int32_t* rowptr, int32_t* colidx);  /* lower triangle of R'HR */
 int mgb_amg_set_c(mgb_amg a, const double* c);     /* n x K row-major cost (f_grid) */
 int mgb_amg_set_z(mgb_amg a, const double* z);     /* S*n, [u; s] */

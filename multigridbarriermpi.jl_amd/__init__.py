@@ -639,6 +639,13 @@ class AMG:
         call("mgb_amg_level_size", self.handle, l, C.byref(N), C.byref(nz))
         return N.value, nz.value
 
+    def chol_info(self, l=None):
+        """Device factorisation of level l (default finest): ranks it is split over, doubles exchanged and launches per
+        Newton system."""
+        sw, ex, la = C.c_int(), C.c_double(), C.c_int()
+        call("mgb_amg_chol_info", self.handle, self.L - 1 if l is None else int(l), C.byref(sw), C.byref(ex), C.byref(la))
+        return dict(split_world=sw.value, exchange_doubles=ex.value, launches=la.value)
+
     def hessian_pattern(self, l):
         N, nz = self.level_size(l)
         rp = np.empty(N + 1, dtype=np.int32)

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "mgb_amg_dims": [H, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p],
     "mgb_amg_local_rows": [H, c_int_p, c_int_p, c_int_p],
     "mgb_amg_prepare": [H, C.c_int],
+    "mgb_amg_chol_info": [H, C.c_int, c_int_p, c_dbl_p, c_int_p],
     "mgb_amg_level_size": [H, C.c_int, c_int_p, c_int_p],
     "mgb_amg_hessian_pattern": [H, C.c_int, c_i32_p, c_i32_p],
     "mgb_amg_set_c": [H, c_dbl_p],

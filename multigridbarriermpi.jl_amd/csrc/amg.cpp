@@ -389,11 +389,19 @@ void Amg::ensure_chol(Level& lv) {
   if (lv.chol_built) return;
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
   lv.chol.analyze(lv.plan.Apat, lv.plan.coords.data(), geo_.dim);
-  lv.gchol.build(lv.chol);
+  lv.gchol.build(lv.chol, &ctx_);      // sharded context: split by subtrees (gpuchol.hpp)
   lv.chol_built = true;
 }
 
 const LevelPlan& Amg::plan(int l) { return level(l).plan; }
+
+void Amg::chol_info(int l, int* split_world, double* exchange_doubles, int* launches) {
+  Level& lv = level(l);
+  ensure_chol(lv);
+  if (split_world) *split_world = lv.gchol.split() ? ctx_.world : 1;
+  if (exchange_doubles) *exchange_doubles = lv.gchol.split() ? lv.gchol.exchange_doubles() : 0.0;
+  if (launches) *launches = lv.gchol.launches_per_solve();
+}
 
 void Amg::prepare(int l) {
   const int L = (int)levels_.size();
@@ -586,8 +594,7 @@ static const double kBeta = 0.5, kArmijo = 0.1, kMinStep = 1e-8;      // oracle 
 void Amg::enqueue_trial(Level& lv, Trial& T, double step, int slot) {
   double* out = scal_.p + 4 + 2 * slot;
   enqueue_f0(lv, lv.s.p, -step, lv.nstep.p, T.s, T.dz, phi_cur_.p, T.phi, out);
-  ctx_.allreduce_sum(out, 2);
-  T.step = step;      // the caller copies scal_[3..7] (inc + both trials) back in one transfer
+  T.step = step;      // the caller reduces scal_[4..7] over the ranks in ONE collective and copies scal_[3..7] back in one transfer
 }
 
 bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, double* inc, Trial* spec,
@@ -614,6 +621,7 @@ bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, do
     if (spec) {
       enqueue_trial(lv, spec[0], 1.0, 0);
       enqueue_trial(lv, spec[1], kBeta, 1);
+      ctx_.allreduce_sum(scal_.p + 4, 4);      // sharded: both trials' partial sums in one collective
       st.n_f0 += 2;
     }
     hip_check(hipMemcpyAsync(h_scal_.p + 3, scal_.p + 3, (spec ? 5 : 1) * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),

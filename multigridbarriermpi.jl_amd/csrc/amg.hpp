@@ -201,6 +201,8 @@ class Amg {
   // structures, so that the next solve() is pure compute
   void prepare(int l);
   const BarrierParams& params() const { return P_; }
+  // device factorisation of level l: ranks it is split over (1 = replicated), doubles exchanged per solve, launches
+  void chol_info(int l, int* split_world, double* exchange_doubles, int* launches);
 
   // problem data: c is n x K row-major, z is the S*n vector [u; s]
   void set_c(const double* c_host);

@@ -622,6 +622,12 @@ int mgb_amg_prepare(mgb_amg a, int level) {
     a->amg->prepare(level);
   });
 }
+int mgb_amg_chol_info(mgb_amg a, int level, int* split_world, double* exchange_doubles, int* launches) {
+  return guard([&] {
+    need(a && level >= 0 && level < a->amg->L(), "level out of range");
+    a->amg->chol_info(level, split_world, exchange_doubles, launches);
+  });
+}
 int mgb_amg_level_size(mgb_amg a, int level, int* N, int* nnz_lower) {
   return guard([&] {
     need(a && level >= 0 && level < a->amg->L(), "level out of range");

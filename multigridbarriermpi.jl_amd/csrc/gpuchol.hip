@@ -840,6 +840,45 @@ __global__ __launch_bounds__(NT) void backward_kernel(const GNode* __restrict__ 
   }
 }
 
+// Split factorisation: the Schur complement of a subtree root -- lower triangle of the boundary block of its front plus
+// the right-hand-side row, column j packed at j (nb + 1) - j (j - 1) / 2 -- into / out of the exchange buffer.  A rank
+// that does not own the subtree contributes zeros, so the sum over the ranks is the owner's block, exactly.
+__global__ __launch_bounds__(256) void schur_pack_kernel(const RootXchg* __restrict__ roots, const double* __restrict__ fronts,
+                                                         double* __restrict__ xb) {
+  const RootXchg r = roots[blockIdx.x];
+  const double* F = fronts + r.off;
+  for (int j = blockIdx.y; j < r.nb; j += gridDim.y) {
+    double* dst = xb + r.xoff + (long long)j * (r.nb + 1) - (long long)j * (j - 1) / 2 - j;      // dst[i], i = j .. nb
+    const double* col = F + (long long)r.ld * (r.ns + j) + r.ns;
+    for (int i = j + threadIdx.x; i <= r.nb; i += blockDim.x) dst[i] = r.owned ? col[i] : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void schur_unpack_kernel(const RootXchg* __restrict__ roots, const double* __restrict__ xb,
+                                                           double* __restrict__ fronts) {
+  const RootXchg r = roots[blockIdx.x];
+  double* F = fronts + r.off;
+  for (int j = blockIdx.y; j < r.nb; j += gridDim.y) {
+    const double* src = xb + r.xoff + (long long)j * (r.nb + 1) - (long long)j * (j - 1) / 2 - j;
+    double* col = F + (long long)r.ld * (r.ns + j) + r.ns;
+    for (int i = j + threadIdx.x; i <= r.nb; i += blockDim.x) col[i] = src[i];
+  }
+}
+
+// x of the unknowns this rank is responsible for (its subtree; rank 0 also the top), zeros elsewhere, + the pivot flag
+__global__ __launch_bounds__(256) void xsol_pack_kernel(int n, const int* __restrict__ own, const double* __restrict__ x,
+                                                        const int* __restrict__ fail, double* __restrict__ xs) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (long long)gridDim.x * blockDim.x)
+    xs[i] = (i == n) ? (*fail ? 1.0 : 0.0) : (own[i] ? x[i] : 0.0);
+}
+
+__global__ __launch_bounds__(256) void xsol_unpack_kernel(int n, const double* __restrict__ xs, double* __restrict__ x, int* fail) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (long long)gridDim.x * blockDim.x) {
+    if (i == n) *fail = xs[n] != 0.0 ? 1 : 0;
+    else x[i] = xs[i];
+  }
+}
+
 }  // namespace
 
 template <class T>
@@ -857,7 +896,11 @@ GpuChol::~GpuChol() {
   for (void* p : allocs_) (void)hipFree(p);
 }
 
-void GpuChol::build(const MfChol& sym) {
+void GpuChol::build(const MfChol& sym, Ctx* ctx) {
+  ctx_ = ctx;
+  part_ = (ctx && ctx->world > 1) ? sym.partition(ctx->world) : CholPartition();
+  if (!part_.split()) part_.owner.assign(sym.nodes_.size(), -1);
+  const int my_rank = ctx ? ctx->rank : 0;
   n_ = sym.n_;
   nnodes_ = (int)sym.nodes_.size();
   flops_ = sym.flops_;
@@ -969,20 +1012,24 @@ void GpuChol::build(const MfChol& sym) {
   std::vector<StartJob> starts;
   std::vector<StepTile> tiles;
   std::vector<RectJob> rects;
-  plan_.assign(nheights_, HeightPlan());
   launches_ = 0;
+  // one schedule per node set: `which` = 0 own nodes (split: this rank's subtree; else everything), 1 = the replicated top
+  auto make_plans = [&](int which, std::vector<HeightPlan>& out) {
+  out.clear();
   for (int h = 0; h < nheights_; ++h) {
-    HeightPlan& hp = plan_[h];
+    HeightPlan hp_new;
+    HeightPlan& hp = hp_new;
     hp.nodes.ofs = (int)lists.size();
     int max_ns = 0;
     hp.max_nf = 0;
     std::vector<int> mine;
     for (int t = 0; t < nnodes_; ++t)
-      if (height[t] == h) {
+      if (height[t] == h && (part_.split() ? (which == 0 ? part_.owner[t] == my_rank : part_.owner[t] < 0) : which == 0)) {
         mine.push_back(t);
         max_ns = std::max(max_ns, nodes[t].ns);
         hp.max_nf = std::max(hp.max_nf, nodes[t].nf);
       }
+    if (mine.empty()) continue;
     lists.insert(lists.end(), mine.begin(), mine.end());
     hp.nodes.cnt = (int)mine.size();
     // leaf heights with small fronts: the whole front in one workgroup (front_leaf_kernel)
@@ -1098,7 +1145,11 @@ void GpuChol::build(const MfChol& sym) {
     }
     hp.rect.cnt = (int)rects.size() - hp.rect.ofs;
     launches_ += 1 + (hp.rect.cnt ? 1 : 0);
+    out.push_back(std::move(hp_new));
   }
+  };
+  make_plans(0, plan_);
+  if (part_.split()) make_plans(1, plan_top_);
   if ((size_t)(max_nf_ + RT + PB) * 8 > 150 * 1024) throw ArgError("gpuchol: front exceeds the LDS budget of the sweeps");
   d_nodes_ = upload(nodes);
   d_perm_ = upload(sym.perm_);
@@ -1111,6 +1162,35 @@ void GpuChol::build(const MfChol& sym) {
   d_tiles_ = upload(tiles);
   d_singles_ = upload(singles);
   d_rectjobs_ = upload(rects);
+  if (part_.split()) {
+    std::vector<RootXchg> roots;
+    long long xoff = 0;
+    for (int j = 0; j < part_.world; ++j) {
+      const GNode& g = nodes[part_.roots[j]];
+      RootXchg r{};
+      r.off = g.off;
+      r.xoff = xoff;
+      r.ld = g.nf + 1;
+      r.ns = g.ns;
+      r.nb = g.nf - g.ns;
+      r.owned = (j == my_rank) ? 1 : 0;
+      xoff += (long long)r.nb * (r.nb + 3) / 2;
+      max_root_nb_ = std::max(max_root_nb_, r.nb);
+      roots.push_back(r);
+    }
+    xchg_doubles_ = xoff;
+    nroots_ = (int)roots.size();
+    d_roots_ = upload(roots);
+    std::vector<int> own(n_, 0);
+    for (int t = 0; t < nnodes_; ++t)
+      if (part_.owner[t] == my_rank || (part_.owner[t] < 0 && my_rank == 0))
+        for (int k = 0; k < nodes[t].ns; ++k) own[sym.perm_[nodes[t].first + k]] = 1;
+    d_own_orig_ = upload(own);
+    ck(hipMalloc((void**)&d_xchg_, std::max<long long>(xchg_doubles_, 1) * sizeof(double)), "hipMalloc xchg");
+    allocs_.push_back(d_xchg_);
+    ck(hipMalloc((void**)&d_xsol_, (size_t)(n_ + 1) * sizeof(double)), "hipMalloc xsol");
+    allocs_.push_back(d_xsol_);
+  }
   ck(hipMalloc((void**)&d_fronts_, std::max<long long>(total_front_, 1) * sizeof(double)), "hipMalloc fronts");
   allocs_.push_back(d_fronts_);
   // the mirrored-L half of every front is written before it is read, but never leave it uninitialised
@@ -1148,6 +1228,10 @@ void GpuChol::factor_solve(hipStream_t st, const double* d_vals, const double* d
   // the pivot flag is re-armed here, outside the captured chain (a memset node replayed from the graph was seen
   // to leave garbage in the flag when another library used the device between replays)
   ck(hipMemsetAsync(d_fail_, 0, sizeof(int), st), "memset flag");
+  if (part_.split()) {      // two collectives inside: plain launches, no graph
+    factor_solve_split(st, d_vals, d_b, d_x, tm);
+    return;
+  }
   if (!use_graph || tm || d_prof_) {
     enqueue(st, d_vals, d_b, d_x, tm);
     return;
@@ -1174,10 +1258,9 @@ void GpuChol::factor_solve(hipStream_t st, const double* d_vals, const double* d
   ck(hipGraphLaunch(ge.exec, st), "hipGraphLaunch");
 }
 
-void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm) {
-  int nprof = 0;
-  for (int h = 0; h < nheights_; ++h) {
-    const HeightPlan& hp = plan_[h];
+void GpuChol::enqueue_forward(hipStream_t st, const std::vector<HeightPlan>& plan, const double* d_vals, const double* d_b,
+                              KernelTimer* tm, int& nprof) {
+  for (const HeightPlan& hp : plan) {
     if (hp.leaf) {
       if (tm) tm->begin(st, KC_CHOL_SINGLE, hp.start_bytes);
       const size_t lds = ((size_t)(hp.max_nf + 1) * hp.max_nf - (size_t)hp.max_nf * (hp.max_nf - 1) / 2) * sizeof(double);
@@ -1207,8 +1290,11 @@ void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, d
       if (tm) tm->end(st);
     }
   }
-  for (int h = nheights_ - 1; h >= 0; --h) {
-    const HeightPlan& hp = plan_[h];
+}
+
+void GpuChol::enqueue_backward(hipStream_t st, const std::vector<HeightPlan>& plan, double* d_x, KernelTimer* tm) {
+  for (int h = (int)plan.size() - 1; h >= 0; --h) {
+    const HeightPlan& hp = plan[h];
     const int use_rect = hp.rect.cnt ? 1 : 0;
     if (use_rect) {
       if (tm) tm->begin(st, KC_CHOL_BWD_RECT, hp.rect_bytes);
@@ -1227,6 +1313,31 @@ void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, d
                          d_x);
     if (tm) tm->end(st);
   }
+}
+
+void GpuChol::factor_solve_split(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm) {
+  int nprof = 0;
+  enqueue_forward(st, plan_, d_vals, d_b, tm, nprof);                    // this rank's subtree
+  const dim3 xg(nroots_, std::max(1, std::min(64, max_root_nb_)));
+  hipLaunchKernelGGL(schur_pack_kernel, xg, dim3(256), 0, st, d_roots_, d_fronts_, d_xchg_);
+  ck(hipGetLastError(), "schur pack");
+  ctx_->allreduce_sum(d_xchg_, xchg_doubles_);                           // every subtree root's Schur complement, everywhere
+  hipLaunchKernelGGL(schur_unpack_kernel, xg, dim3(256), 0, st, d_roots_, d_xchg_, d_fronts_);
+  enqueue_forward(st, plan_top_, d_vals, d_b, tm, nprof);                // replicated top: same arithmetic on every rank
+  enqueue_backward(st, plan_top_, d_x, tm);
+  enqueue_backward(st, plan_, d_x, tm);
+  const int grid = std::min(2048, (n_ + 256) / 256);
+  hipLaunchKernelGGL(xsol_pack_kernel, dim3(grid), dim3(256), 0, st, n_, d_own_orig_, d_x, d_fail_, d_xsol_);
+  ck(hipGetLastError(), "xsol pack");
+  ctx_->allreduce_sum(d_xsol_, (long long)n_ + 1);                       // x (one contributor per unknown) + pivot flag
+  hipLaunchKernelGGL(xsol_unpack_kernel, dim3(grid), dim3(256), 0, st, n_, d_xsol_, d_x, d_fail_);
+  ck(hipGetLastError(), "factor_solve_split launches");
+}
+
+void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm) {
+  int nprof = 0;
+  enqueue_forward(st, plan_, d_vals, d_b, tm, nprof);
+  enqueue_backward(st, plan_, d_x, tm);
   ck(hipGetLastError(), "factor_solve launches");
   if (d_prof_) {      // debugging aid: phase stamps of workgroup 0 of every factorisation launch, in units of 10 ns
     ck(hipStreamSynchronize(st), "prof sync");

@@ -31,6 +31,14 @@
 namespace mgb {
 
 class KernelTimer;   // amg.hpp: optional HIP-event bracketing of individual launches
+struct Ctx;          // amg.hpp: device, stream and (sharded jobs) the allreduce callback
+
+struct RootXchg {     // one subtree root of a split factorisation: where its Schur complement lives and travels
+  long long off;      // front offset
+  long long xoff;     // offset of its packed lower triangle (+ right-hand-side row) in the exchange buffer
+  int ld, ns, nb;     // leading dimension nf + 1, own columns, boundary size
+  int owned;          // 1 on the rank that factors this subtree
+};
 
 struct GNode {
   long long off;      // offset of the (nf+1) x (nf+1) column-major front
@@ -73,7 +81,14 @@ class GpuChol {
   GpuChol(const GpuChol&) = delete;
   GpuChol& operator=(const GpuChol&) = delete;
   ~GpuChol();
-  void build(const MfChol& sym);
+  // ctx (nullable): on a sharded context (ctx->world a power of two the tree can be split into) the factorisation is
+  // split by subtrees -- this rank factors its subtree, the subtree roots' Schur complements (with their right-hand-side
+  // rows) are summed over the ranks (one rank contributes each), every rank factors the replicated top and sweeps back
+  // through the top and its own subtree, and a second allreduce assembles x and the pivot flag.  Bitwise the same
+  // arithmetic as the unsplit factorisation.
+  void build(const MfChol& sym, Ctx* ctx = nullptr);
+  bool split() const { return part_.split(); }
+  double exchange_doubles() const { return (double)xchg_doubles_ + n_ + 1; }
   // d_x = A^{-1} d_b: d_vals = device lower-triangle values in the pattern order given to MfChol::analyze,
   // d_b / d_x device vectors in the ORIGINAL ordering (may alias).
   void factor_solve(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* timer = nullptr);
@@ -87,6 +102,19 @@ class GpuChol {
   template <class T>
   T* upload(const std::vector<T>& v);
   void enqueue(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* timer);
+  struct HeightPlan;
+  void enqueue_forward(hipStream_t st, const std::vector<HeightPlan>& plan, const double* d_vals, const double* d_b, KernelTimer* tm,
+                       int& nprof);
+  void enqueue_backward(hipStream_t st, const std::vector<HeightPlan>& plan, double* d_x, KernelTimer* tm);
+  void factor_solve_split(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm);
+  Ctx* ctx_ = nullptr;
+  CholPartition part_;
+  long long xchg_doubles_ = 0;
+  RootXchg* d_roots_ = nullptr;
+  int nroots_ = 0, max_root_nb_ = 0;
+  double* d_xchg_ = nullptr;      // Schur exchange buffer
+  double* d_xsol_ = nullptr;      // n + 1: masked solution + pivot flag
+  int* d_own_orig_ = nullptr;     // per unknown (original ordering): 1 if this rank contributes it to the assembled x
   struct GraphEntry {      // captured launch chain for one (values, rhs, solution) pointer triple
     const double* vals;
     const double* b;
@@ -132,7 +160,8 @@ class GpuChol {
     bool narrow = false; // single && at most 8 pivots per front
     bool leaf = false;   // small childless fronts: front_leaf does the whole front in one workgroup
   };
-  std::vector<HeightPlan> plan_;
+  std::vector<HeightPlan> plan_;       // own nodes (everything when the factorisation is not split)
+  std::vector<HeightPlan> plan_top_;   // split only: the replicated separators above the subtrees
   std::vector<void*> allocs_;
 };
 

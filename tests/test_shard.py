@@ -160,7 +160,8 @@ def _gpu_worker(rank, world, port, q, kind, L, p):
         be.set_comm(rank, world, M.torch_allreduce(dist, 0))
         sol = getattr(M, kind + "_mpi_solve")(L=L, p=p)
         z = M.mpi_to_native(sol).z
-        q.put((rank, z, np.asarray(sol.SOL_main["its"]), be.comm_stats()))
+        info = M.AMG(getattr(M, kind + "_mpi")(L, backend=be), p=p).chol_info()
+        q.put((rank, z, np.asarray(sol.SOL_main["its"]), dict(be.comm_stats(), **info)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -175,6 +176,10 @@ def test_sharded_solve_matches_unsharded_two_processes_one_gpu(gpu_required, kin
     (r0, z0, its0, st0), (r1, z1, its1, st1) = out
     assert np.array_equal(z0, z1) and np.array_equal(its0, its1)          # ranks stay in lock step, bit for bit
     assert st0["calls"] == st1["calls"] > 0
+    # the factorisation itself is split over the two ranks (one nested-dissection subtree each, replicated top)
+    # (fem1d L=4 has 32 unknowns: one leaf front, nothing to split -- replicated there)
+    want = 2 if kind == "fem2d" else 1
+    assert st0["split_world"] == st1["split_world"] == want and (st0["exchange_doubles"] > 0) == (want == 2)
     assert np.linalg.norm(z0 - ref) <= 1e-10 * np.linalg.norm(ref)
 
 
