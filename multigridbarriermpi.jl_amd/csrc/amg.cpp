@@ -1,5 +1,7 @@
 #include "amg.hpp"
 
+#include <immintrin.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -329,6 +331,10 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
   h_flag_.alloc(4);
   scal_.alloc(8);
   h_scal_.alloc(8);
+  seq_dev_.alloc(1);
+  hip_check(hipMemset(seq_dev_.p, 0, sizeof(unsigned long long)), "memset seq");
+  h_seq_.alloc(1);
+  h_seq_.p[0] = 0;
   hip_check(hipMemsetAsync(c_.p, 0, c_.n * sizeof(double), ctx_.stream), "memset");
   hip_check(hipMemsetAsync(z_.p, 0, z_.n * sizeof(double), ctx_.stream), "memset");
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
@@ -351,10 +357,11 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
   int maxN = 0;
   for (auto& lv : levels_) maxN = std::max(maxN, lv->plan.N);
   partials_.alloc(reduction_scratch_doubles(n_, maxN));
+  hip_check(hipMemset(partials_.p, 0, partials_.n * sizeof(double)), "memset scratch");      // ticket word starts at zero
 }
 
 size_t reduction_scratch_doubles(int n_local, int max_level_unknowns) {
-  return (size_t)2 * std::max(f0_blocks(n_local), f0_blocks(max_level_unknowns)) + 16;
+  return (size_t)2 * std::max(f0_blocks(n_local), f0_blocks(max_level_unknowns)) + 8 + kReductionHeader;      // incl. the ticket words
 }
 
 Amg::Level& Amg::level(int l) {
@@ -492,6 +499,33 @@ void Amg::sync_collect(const char* what) {
   if (live_) timer_.collect(*live_);
 }
 
+HostSignal Amg::next_signal() {
+  HostSignal sig;
+  if (ctx_.world != 1) return sig;
+  sig.seq_dev = seq_dev_.p;
+  sig.seq_host = h_seq_.p;
+  ++seq_expected_;
+  return sig;
+}
+
+void Amg::wait_signal(const char* what) {
+  // sampled steps bracket their launches with HIP events, which only a stream synchronisation resolves
+  // ... and the host solver waits for copies that follow the signalling launch on the stream
+  if (ctx_.world != 1 || host_solve_ || (live_ && timer_.sampling())) {
+    sync_collect(what);
+    return;
+  }
+  const volatile unsigned long long* q = h_seq_.p;
+  const double t0 = now_s();
+  for (unsigned long spins = 0; __atomic_load_n(q, __ATOMIC_ACQUIRE) < seq_expected_; ++spins) {
+    _mm_pause();
+    if ((spins & 0xfffff) == 0xfffff && now_s() - t0 > 10.0) {      // a faulted kernel never signals: surface the HIP error
+      hip_check(hipStreamSynchronize(ctx_.stream), what);
+      if (__atomic_load_n(q, __ATOMIC_ACQUIRE) < seq_expected_) throw InternalError(std::string("mgb: completion signal lost in ") + what);
+    }
+  }
+}
+
 void Amg::refresh_dz0() { launch_spmv(ctx_.stream, Dstack_.view, z_.p, nullptr, Dz0_.p); }
 
 void Amg::dev_apply(Level& lv, const double* s_dev, double* dz) {
@@ -510,11 +544,11 @@ double Amg::trial_bytes(const Level& lv, bool with_ref) const {
 // in ONE fused launch; beyond that the three bandwidth-shaped kernels are faster (at fem2d L=9 the fused kernel
 // reaches 24 % of HBM peak, apply_D + barrier_f0 43 % each) and launch gaps no longer matter.
 void Amg::enqueue_f0(Level& lv, const double* s_dev, double alpha, const double* nstep, double* s_out, double* dz,
-                     const double* phi_ref, double* phi_out, double* out2) {
+                     const double* phi_ref, double* phi_out, double* out2, HostSignal sig) {
   if (n_ <= fused_trial_rows_) {
     timer_.begin(ctx_.stream, KC_F0, trial_bytes(lv, phi_ref != nullptr));
     launch_trial_f0(ctx_.stream, lv.B.view, n_, P_, s_dev, alpha, nstep, s_out, Dz0_.p, dz, w_.p, c_.p, phi_ref,
-                    kFracToBoundary, phi_out, partials_.p, out2);
+                    kFracToBoundary, phi_out, partials_.p, out2, host_scal(out2), sig);
     timer_.end(ctx_.stream);
     return;
   }
@@ -525,7 +559,7 @@ void Amg::enqueue_f0(Level& lv, const double* s_dev, double alpha, const double*
   }
   dev_apply(lv, x, dz);
   timer_.begin(ctx_.stream, KC_F0, (double)n_ * (2 * P_.K + 2 + (phi_ref ? 1 : 0)) * 8);
-  launch_barrier_f0(ctx_.stream, n_, P_, dz, w_.p, c_.p, phi_ref, kFracToBoundary, phi_out, partials_.p, out2);
+  launch_barrier_f0(ctx_.stream, n_, P_, dz, w_.p, c_.p, phi_ref, kFracToBoundary, phi_out, partials_.p, out2, host_scal(out2), sig);
   timer_.end(ctx_.stream);
 }
 
@@ -533,10 +567,12 @@ double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts, cons
                    double* dz, double alpha, const double* nstep, double* s_out) {
   // objective at x = s_dev + alpha * nstep (x = s_dev without nstep), Dz(x) left in dz.
   // phi_ref == nullptr: start of a Newton solve (records phi of the iterate); otherwise a line-search trial
-  enqueue_f0(lv, s_dev, alpha, nstep, s_out, dz, phi_ref, phi_out, scal_.p);
-  ctx_.allreduce_sum(scal_.p, 2);      // sharded: +inf (a row left the cone on some rank) survives the sum
-  hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
-  sync_collect("sync f0");
+  enqueue_f0(lv, s_dev, alpha, nstep, s_out, dz, phi_ref, phi_out, scal_.p, next_signal());
+  if (ctx_.world > 1) {      // single GPU: the kernel wrote h_scal_ itself (host_scal)
+    ctx_.allreduce_sum(scal_.p, 2);      // sharded: +inf (a row left the cone on some rank) survives the sum
+    hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
+  }
+  wait_signal("sync f0");
   if (parts) {
     parts[0] = h_scal_.p[0];
     parts[1] = h_scal_.p[1];
@@ -568,8 +604,9 @@ double Amg::dev_f1(Level& lv, const double* dz, double t, double* g_out, SolveSt
   launch_spmv(ctx_.stream, lv.BT.view, v_.p, nullptr, g_out);
   timer_.end(ctx_.stream);
   ctx_.allreduce_sum(g_out, lv.plan.N);      // sharded: interface dofs are summed across the row blocks
-  launch_dot(ctx_.stream, lv.plan.N, g_out, g_out, partials_.p, scal_.p + 2);
-  hip_check(hipMemcpyAsync(h_scal_.p + 2, scal_.p + 2, sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H gg");
+  launch_dot(ctx_.stream, lv.plan.N, g_out, g_out, partials_.p, scal_.p + 2, host_scal(scal_.p + 2), nullptr, nullptr, next_signal());
+  if (ctx_.world > 1)
+    hip_check(hipMemcpyAsync(h_scal_.p + 2, scal_.p + 2, sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H gg");
   if (host_solve_)
     hip_check(hipMemcpyAsync(lv.h_g.p, g_out, (size_t)lv.plan.N * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
               "D2H g");
@@ -579,9 +616,10 @@ double Amg::dev_f1(Level& lv, const double* dz, double t, double* g_out, SolveSt
     hip_check(hipEventRecord(ev_f1_, ctx_.stream), "record f1");
     enqueue_f2_assemble(lv, dz, *st);
     *pre = dz;
-    hip_check(hipEventSynchronize(ev_f1_), "sync f1 event");      // timer events are collected at the next full sync
+    if (ctx_.world == 1) wait_signal("sync f1");      // |g| is on the host; the Hessian assembly keeps running behind it
+    else hip_check(hipEventSynchronize(ev_f1_), "sync f1 event");      // timer events are collected at the next full sync
   } else {
-    sync_collect("sync f1");
+    wait_signal("sync f1");
   }
   return std::sqrt(h_scal_.p[2]);
 }
@@ -591,10 +629,48 @@ double Amg::dev_f1(Level& lv, const double* dz, double t, double* g_out, SolveSt
 static const double kBeta = 0.5, kArmijo = 0.1, kMinStep = 1e-8;      // oracle BETA, ARMIJO, MIN_STEP
 
 // enqueue (no host sync): T.s = s - step * nstep, f0 there -> host slot h_scal_[4 + 2 slot .. +1]
-void Amg::enqueue_trial(Level& lv, Trial& T, double step, int slot) {
+void Amg::enqueue_trial(Level& lv, Trial& T, double step, int slot, HostSignal sig) {
   double* out = scal_.p + 4 + 2 * slot;
-  enqueue_f0(lv, lv.s.p, -step, lv.nstep.p, T.s, T.dz, phi_cur_.p, T.phi, out);
+  enqueue_f0(lv, lv.s.p, -step, lv.nstep.p, T.s, T.dz, phi_cur_.p, T.phi, out, sig);
   T.step = step;      // the caller reduces scal_[4..7] over the ranks in ONE collective and copies scal_[3..7] back in one transfer
+}
+
+void Amg::launch_step_graph(Level& lv, Trial* spec) {
+  const void* key[12] = {lv.avals.p, lv.g.p, lv.nstep.p, lv.s.p, spec[0].s, spec[0].phi, spec[0].dz,
+                         spec[1].s,  spec[1].phi, spec[1].dz, phi_cur_.p, Dz0_.p};
+  for (const auto& g : lv.step_graphs)
+    if (std::equal(key, key + 12, g.key)) {
+      hip_check(hipGraphLaunch(g.exec, ctx_.stream), "hipGraphLaunch");
+      ++seq_expected_;      // the second trial of the graph signals
+      spec[0].step = 1.0;
+      spec[1].step = kBeta;
+      return;
+    }
+  hipGraph_t graph = nullptr;
+  hip_check(hipStreamBeginCapture(ctx_.stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+  try {
+    lv.gchol.enqueue_chain(ctx_.stream, lv.avals.p, lv.g.p, lv.nstep.p);
+    launch_dot(ctx_.stream, lv.plan.N, lv.g.p, lv.nstep.p, partials_.p, scal_.p + 3, host_scal(scal_.p + 3), lv.gchol.fail_flag(),
+               h_flag_.p);
+    enqueue_trial(lv, spec[0], 1.0, 0);
+    HostSignal sig;      // baked into the graph: the device counter advances on every replay
+    sig.seq_dev = seq_dev_.p;
+    sig.seq_host = h_seq_.p;
+    enqueue_trial(lv, spec[1], kBeta, 1, sig);
+  } catch (...) {
+    (void)hipStreamEndCapture(ctx_.stream, &graph);
+    if (graph) (void)hipGraphDestroy(graph);
+    throw;
+  }
+  hip_check(hipStreamEndCapture(ctx_.stream, &graph), "hipStreamEndCapture");
+  Level::StepGraph sg{};
+  std::copy(key, key + 12, sg.key);
+  hipError_t e = hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  hip_check(e, "hipGraphInstantiate");
+  lv.step_graphs.push_back(sg);
+  hip_check(hipGraphLaunch(sg.exec, ctx_.stream), "hipGraphLaunch");
+  ++seq_expected_;
 }
 
 bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, double* inc, Trial* spec,
@@ -606,35 +682,55 @@ bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, do
   // event pairs cost ~14 % of a solve when every launch is bracketed: time every 8th Newton step only
   timer_.sample((st.n_factor % 8) == 1);
   if (!host_solve_) {
-    // device multifrontal factorisation + sweeps: nothing but two scalars and a flag cross PCIe
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (live_) {
-      hip_check(hipEventCreate(&e0), "event");
-      hip_check(hipEventCreate(&e1), "event");
-      hip_check(hipEventRecord(e0, ctx_.stream), "record");
-    }
+    // device multifrontal factorisation + sweeps: nothing but a few scalars and a flag cross PCIe.  Three launch modes:
+    //   sampled steps (every 8th, when timing is on): plain launches bracketed by HIP events (KernelTimer);
+    //   single GPU otherwise: ONE hipGraph launch for chain + <g, n> + both speculative trials (launch_step_graph);
+    //   sharded: chain (split by subtrees, two collectives inside), then dot and trials with their collectives.
+    static const bool use_graph = [] {
+      const char* e = std::getenv("MGB_CHOL_GRAPH");
+      return !(e && e[0] == '0');
+    }();
     KernelTimer* tm = (live_ && timer_.sampling()) ? &timer_ : nullptr;
-    lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g.p, lv.nstep.p, tm);
-    if (live_) hip_check(hipEventRecord(e1, ctx_.stream), "record");
-    launch_dot(ctx_.stream, N, lv.g.p, lv.nstep.p, partials_.p, scal_.p + 3);
-    hip_check(hipMemcpyAsync(h_flag_.p, lv.gchol.fail_flag(), sizeof(int), hipMemcpyDeviceToHost, ctx_.stream), "D2H flag");
-    if (spec) {
-      enqueue_trial(lv, spec[0], 1.0, 0);
-      enqueue_trial(lv, spec[1], kBeta, 1);
-      ctx_.allreduce_sum(scal_.p + 4, 4);      // sharded: both trials' partial sums in one collective
+    const bool flag_rides = ctx_.world == 1;      // the dot kernel behind the chain hands the pivot flag to the host and re-arms it
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (flag_rides && spec && !tm && use_graph && lv.flag_armed) {
+      launch_step_graph(lv, spec);
       st.n_f0 += 2;
+    } else {
+      if (tm) {      // the chain's own time, scaled by the sampling period in `time_factor`
+        hip_check(hipEventCreate(&e0), "event");
+        hip_check(hipEventCreate(&e1), "event");
+        hip_check(hipEventRecord(e0, ctx_.stream), "record");
+      }
+      lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g.p, lv.nstep.p, tm, /*flag_armed=*/flag_rides && lv.flag_armed);
+      if (tm) hip_check(hipEventRecord(e1, ctx_.stream), "record");
+      if (flag_rides) {
+        launch_dot(ctx_.stream, N, lv.g.p, lv.nstep.p, partials_.p, scal_.p + 3, host_scal(scal_.p + 3), lv.gchol.fail_flag(),
+                   h_flag_.p, spec ? HostSignal() : next_signal());
+        lv.flag_armed = true;
+      } else {
+        launch_dot(ctx_.stream, N, lv.g.p, lv.nstep.p, partials_.p, scal_.p + 3);
+        hip_check(hipMemcpyAsync(h_flag_.p, lv.gchol.fail_flag(), sizeof(int), hipMemcpyDeviceToHost, ctx_.stream), "D2H flag");
+      }
+      if (spec) {
+        enqueue_trial(lv, spec[0], 1.0, 0);
+        enqueue_trial(lv, spec[1], kBeta, 1, next_signal());
+        ctx_.allreduce_sum(scal_.p + 4, 4);      // sharded: both trials' partial sums in one collective
+        st.n_f0 += 2;
+      }
+      if (ctx_.world > 1)
+        hip_check(hipMemcpyAsync(h_scal_.p + 3, scal_.p + 3, (spec ? 5 : 1) * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
+                  "D2H inc + trials");
     }
-    hip_check(hipMemcpyAsync(h_scal_.p + 3, scal_.p + 3, (spec ? 5 : 1) * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
-              "D2H inc + trials");
-    sync_collect("sync solve");
+    wait_signal("sync solve");
     if (spec)
       for (int q = 0; q < 2; ++q) {
         spec[q].y = h_scal_.p[4 + 2 * q] + t * h_scal_.p[5 + 2 * q];
         spec[q].valid = true;
       }
-    if (live_) {
+    if (e0) {      // sampled step: stands for the 8 steps of its sampling period
       float ms = 0;
-      if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) st.time_factor += ms * 1e-3;
+      if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) st.time_factor += 8.0 * ms * 1e-3;
       (void)hipEventDestroy(e0);
       (void)hipEventDestroy(e1);
     }
@@ -822,9 +918,11 @@ bool Amg::amgb_step(double t, double lam_tol, int max_newton, std::vector<long l
 }
 
 double Amg::c_dot_dz() {
-  launch_barrier_f0(ctx_.stream, n_, P_, Dz0_.p, w_.p, c_.p, nullptr, 0.0, nullptr, partials_.p, scal_.p);
-  ctx_.allreduce_sum(scal_.p, 2);
-  hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
+  launch_barrier_f0(ctx_.stream, n_, P_, Dz0_.p, w_.p, c_.p, nullptr, 0.0, nullptr, partials_.p, scal_.p, host_scal(scal_.p));
+  if (ctx_.world > 1) {
+    ctx_.allreduce_sum(scal_.p, 2);
+    hip_check(hipMemcpyAsync(h_scal_.p, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H scal");
+  }
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   return h_scal_.p[1];
 }
@@ -951,6 +1049,7 @@ bool Amg::solve_device(int l, const double* avals, const double* g, double* nste
   lv.avals.upload(avals, lv.plan.Apat.nnz());
   lv.g_trial.upload(g, lv.plan.N);
   lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g_trial.p, lv.nstep.p);
+  lv.flag_armed = false;      // this path leaves the flag as the factorisation set it
   hip_check(hipMemcpyAsync(h_flag_.p, lv.gchol.fail_flag(), sizeof(int), hipMemcpyDeviceToHost, ctx_.stream), "D2H flag");
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   lv.nstep.download(nstep, lv.plan.N);
@@ -1011,6 +1110,7 @@ Amg::KernelTimes Amg::time_kernels(int l, int reps, int nrot) {
     hip_check(hipMemsetAsync(q->phi.p, 0, q->phi.n * sizeof(double), ctx_.stream), "memset phi");
     q->phi2.alloc((size_t)n_ * P_.ncones);
     q->partials.alloc(partials_.n);
+    hip_check(hipMemsetAsync(q->partials.p, 0, q->partials.n * sizeof(double), ctx_.stream), "memset scratch");
     q->scal.alloc(8);
     sets.push_back(std::move(q));
   }

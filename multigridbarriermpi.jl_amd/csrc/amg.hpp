@@ -236,6 +236,16 @@ class Amg {
  private:
   struct Level {
     bool built = false, chol_built = false;
+    bool flag_armed = false;      // the pivot flag of gchol is known to be zero (re-armed by the dot kernel of the last solve)
+    // captured Newton-step graphs (factorisation chain + <g, n> + both speculative trials), one per set of buffer pointers
+    struct StepGraph {
+      const void* key[12];
+      hipGraphExec_t exec;
+    };
+    std::vector<StepGraph> step_graphs;
+    ~Level() {
+      for (auto& g : step_graphs) (void)hipGraphExecDestroy(g.exec);
+    }
     LevelPlan plan;
     DevCsrOwned R, B, BT, T;
     MfChol chol;      // symbolic structure (+ host numeric path)
@@ -258,7 +268,7 @@ class Amg {
   double trial_bytes(const Level& lv, bool with_ref) const;
   int fused_trial_rows_ = 64 * 2048;      // trial_f0_kernel on launch-bound meshes (env MGB_FUSED_TRIAL_ROWS)
   void enqueue_f0(Level& lv, const double* s_dev, double alpha, const double* nstep, double* s_out, double* dz,
-                  const double* phi_ref, double* phi_out, double* out2);      // no host sync
+                  const double* phi_ref, double* phi_out, double* out2, HostSignal sig = HostSignal());      // no host sync
   // gradient from the Dz of the point; returns |g|.  pre != nullptr: also assembles the point's Hessian values behind it
   double dev_f1(Level& lv, const double* dz, double t, double* g_out, SolveStats* st = nullptr, const double** pre = nullptr);
   void enqueue_f2_assemble(Level& lv, const double* dz, SolveStats& st);
@@ -282,7 +292,10 @@ class Amg {
   // same host synchronisation: two fewer round trips per Newton step.
   bool dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, double* inc, Trial* spec = nullptr,
                     const double* pre_assembled = nullptr);
-  void enqueue_trial(Level& lv, Trial& T, double step, int slot);
+  void enqueue_trial(Level& lv, Trial& T, double step, int slot, HostSignal sig = HostSignal());
+  // single GPU, device solver: factorisation chain, <g, n> (+ pivot flag hand-over) and both speculative trials as ONE
+  // hipGraph launch (one per set of buffer pointers; the trial buffers rotate through at most a dozen combinations)
+  void launch_step_graph(Level& lv, Trial* spec);
   NewtonResult newton(int l, double t, bool finest, double lam_tol, int maxit, SolveStats& st, int verbose);
   bool amgb_step(double t, double lam_tol, int max_newton, std::vector<long long>& its, SolveStats& st, int verbose);
   double c_dot_dz();
@@ -305,6 +318,16 @@ class Amg {
   KernelTimer timer_;
   SolveStats* live_ = nullptr;   // stats object receiving kernel timings during solve()
   void sync_collect(const char* what);
+  // Completion signals (single GPU): the last reduction launch of a batch bumps a sequence number in pinned host memory
+  // (kernels.hpp: HostSignal); wait_signal() polls it instead of an interrupt-driven stream synchronisation.
+  DevBuf<unsigned long long> seq_dev_;
+  PinnedBuf<unsigned long long> h_seq_;
+  unsigned long long seq_expected_ = 0;
+  HostSignal next_signal();           // the signal to attach to a launch (null pair on a sharded context); counts it as expected
+  void wait_signal(const char* what); // returns when every signalled launch so far has delivered its results to the host
+  // pinned-host twin of a slot of scal_ on a single GPU (the reduction kernels write it themselves: no copy launch);
+  // null on a sharded context, where the slot is reduced over the ranks first and copied back afterwards
+  double* host_scal(double* dev_slot) const { return ctx_.world == 1 ? h_scal_.p + (dev_slot - scal_.p) : nullptr; }
 };
 
 }  // namespace mgb

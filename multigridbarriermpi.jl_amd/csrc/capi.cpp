@@ -200,12 +200,13 @@ double reduce_scalar(mgb_vec x, Launch&& launch) {
   hipStream_t st = x->ctx->ctx.stream;
   const int nb = f0_blocks(x->n);
   DevBuf<double> scratch;
-  scratch.alloc((size_t)nb + 1);
-  launch(st, scratch.p, scratch.p + nb);
+  scratch.alloc((size_t)kReductionHeader + nb + 1);      // ticket words | partials | result
+  hip_check(hipMemsetAsync(scratch.p, 0, kReductionHeader * sizeof(double), st), "memset ticket");
+  launch(st, scratch.p, scratch.p + kReductionHeader + nb);
   hip_check(hipGetLastError(), "reduction launch");
   hip_check(hipStreamSynchronize(st), "sync reduction");
   double out = 0.0;
-  hip_check(hipMemcpy(&out, scratch.p + nb, sizeof(double), hipMemcpyDeviceToHost), "D2H");
+  hip_check(hipMemcpy(&out, scratch.p + kReductionHeader + nb, sizeof(double), hipMemcpyDeviceToHost), "D2H");
   return out;
 }
 

@@ -1219,7 +1219,7 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
 // The whole chain is launch-bound (83 dependent launches at fem2d L=7), so it is captured once per
 // (values, rhs, solution) pointer triple into a hipGraph and replayed with ONE host call per Newton step; the
 // event-timed and phase-stamped variants (KernelTimer, MGB_CHOL_PROF) and MGB_CHOL_GRAPH=0 use plain launches.
-void GpuChol::factor_solve(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm) {
+void GpuChol::factor_solve(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm, bool flag_armed) {
   if (n_ == 0) return;
   static const bool use_graph = [] {
     const char* e = std::getenv("MGB_CHOL_GRAPH");
@@ -1227,7 +1227,7 @@ void GpuChol::factor_solve(hipStream_t st, const double* d_vals, const double* d
   }();
   // the pivot flag is re-armed here, outside the captured chain (a memset node replayed from the graph was seen
   // to leave garbage in the flag when another library used the device between replays)
-  ck(hipMemsetAsync(d_fail_, 0, sizeof(int), st), "memset flag");
+  if (!flag_armed) ck(hipMemsetAsync(d_fail_, 0, sizeof(int), st), "memset flag");
   if (part_.split()) {      // two collectives inside: plain launches, no graph
     factor_solve_split(st, d_vals, d_b, d_x, tm);
     return;
@@ -1313,6 +1313,15 @@ void GpuChol::enqueue_backward(hipStream_t st, const std::vector<HeightPlan>& pl
                          d_x);
     if (tm) tm->end(st);
   }
+}
+
+void GpuChol::enqueue_chain(hipStream_t st, const double* d_vals, const double* d_b, double* d_x) {
+  if (part_.split()) throw InternalError("gpuchol: a split factorisation cannot be captured");
+  if (n_ == 0) return;
+  int nprof = 0;
+  enqueue_forward(st, plan_, d_vals, d_b, nullptr, nprof);
+  enqueue_backward(st, plan_, d_x, nullptr);
+  ck(hipGetLastError(), "chain launches");
 }
 
 void GpuChol::factor_solve_split(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm) {

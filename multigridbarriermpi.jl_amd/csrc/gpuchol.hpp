@@ -91,7 +91,12 @@ class GpuChol {
   double exchange_doubles() const { return (double)xchg_doubles_ + n_ + 1; }
   // d_x = A^{-1} d_b: d_vals = device lower-triangle values in the pattern order given to MfChol::analyze,
   // d_b / d_x device vectors in the ORIGINAL ordering (may alias).
-  void factor_solve(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* timer = nullptr);
+  // flag_armed: the caller guarantees the pivot flag is zero (it re-arms it itself behind the chain): no memset launch
+  void factor_solve(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* timer = nullptr,
+                    bool flag_armed = false);
+  // the bare launch chain (no flag re-arm, no graph of its own): for callers that capture it into a larger graph together
+  // with what follows the solve.  Not for split factorisations (their collectives cannot be captured).
+  void enqueue_chain(hipStream_t st, const double* d_vals, const double* d_b, double* d_x);
   int* fail_flag() const { return d_fail_; }   // device int: nonzero after factor_solve() if a pivot was not positive
   int size() const { return n_; }
   double front_bytes() const { return (double)total_front_ * 8; }

@@ -104,14 +104,58 @@ __device__ inline double block_sum(double v, double* lds) {
   return r;
 }
 
-__global__ __launch_bounds__(kBlock) void final_sum_kernel(int nparts, int nout, const double* __restrict__ partials,
-                                                            double* out) {
-  __shared__ double lds[kBlock / 64];
-  for (int o = 0; o < nout; ++o) {
+// Grid-wide sum of per-block partial results WITHOUT a second launch: thread 0 of every block publishes its `NOUT` values
+// (write-through sc1 stores, drained), then takes a ticket; the block whose ticket is the last one reads all partials
+// back (sc1 loads, bypassing its L1) and sums them in a FIXED order -- thread-strided, then the block tree -- so the
+// result does not depend on which block finishes last.  This is the "agent-scope atomic add by one lane of each storing
+// workgroup, last adder consumes" hand-off of MI355X_MICROARCH.md (Valid forms; no L2 write-back, no L1 invalidate).
+// One counter serialises its arrivals (~12 ns each: 11 us for the 896 blocks of the fused objective kernel at fem2d L=7,
+// measured), so the ticket is two-level: 8 shard counters (block id mod 8: one XCD each under round-robin placement, for
+// speed only) on cache lines of their own, whose last arrivers meet on a top counter.
+// scratch layout: kTicketDoubles doubles of ticket words (zero between launches), then the partials.
+// out_dev / out_host (either may be null): device result for a following collective, pinned host memory for the host.
+constexpr int kTicketDoubles = kReductionHeader;      // 9 counters, one 128-byte line each (atomics on one line serialise)
+constexpr int kTicketStride = 32;                     // unsigned words per line
+static_assert(kReductionHeader * sizeof(double) >= 9 * kTicketStride * sizeof(unsigned), "ticket words");
+template <int NOUT>
+__device__ inline void grid_finish(const double (&r)[NOUT] /* valid in thread 0 */, double* scratch, double* out_dev,
+                                   double* out_host, double* lds, HostSignal sig = HostSignal()) {
+  __shared__ int is_last;
+  unsigned* ticket = reinterpret_cast<unsigned*>(scratch);      // counter k lives at ticket[kTicketStride * k]: a 128-byte line each
+  double* partials = scratch + kTicketDoubles;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+      __hip_atomic_store(&partials[(size_t)blockIdx.x * NOUT + o], r[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned shard = blockIdx.x & 7u, nshards = gridDim.x < 8u ? gridDim.x : 8u;
+    const unsigned in_shard = (gridDim.x - shard + 7u) / 8u;      // blocks with this shard id
+    bool last = false;
+    if (__hip_atomic_fetch_add(&ticket[kTicketStride * shard], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+      __hip_atomic_store(&ticket[kTicketStride * shard], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm
+      last = __hip_atomic_fetch_add(&ticket[kTicketStride * 8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nshards - 1;
+      if (last) __hip_atomic_store(&ticket[kTicketStride * 8], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    is_last = last;
+  }
+  __syncthreads();
+  if (!is_last) return;      // workgroup-uniform
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
     double acc = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += kBlock) acc += partials[(size_t)i * nout + o];
-    double r = block_sum(acc, lds);
-    if (threadIdx.x == 0) out[o] = r;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock)
+      acc += __hip_atomic_load(&partials[(size_t)i * NOUT + o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double tot = block_sum(acc, lds);
+    if (threadIdx.x == 0) {
+      if (out_dev) out_dev[o] = tot;
+      if (out_host) __hip_atomic_store(&out_host[o], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (sig.seq_host && threadIdx.x == 0) {      // results first (drained), then the sequence number the host polls
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long q = __hip_atomic_load(sig.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    __hip_atomic_store(sig.seq_dev, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(sig.seq_host, q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -152,7 +196,8 @@ __global__ __launch_bounds__(kBlock) void barrier_f0_kernel(int n, BarrierParams
                                                              const double* __restrict__ w,
                                                              const double* __restrict__ c,
                                                              const double* __restrict__ phi_ref, double frac,
-                                                             double* __restrict__ phi_out, double* partials) {
+                                                             double* __restrict__ phi_out, double* scratch,
+                                                             double* out_dev, double* out_host, HostSignal sig) {
   __shared__ double lds[kBlock / 64];
   double accF = 0.0, accL = 0.0;
   for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < n; q += (long long)gridDim.x * kBlock) {
@@ -171,12 +216,8 @@ __global__ __launch_bounds__(kBlock) void barrier_f0_kernel(int n, BarrierParams
     for (int j = 0; j < P.K; ++j) lin += cq[j] * dz[j];
     accL += wq * lin;
   }
-  double rF = block_sum(accF, lds);
-  double rL = block_sum(accL, lds);
-  if (threadIdx.x == 0) {
-    partials[2 * blockIdx.x] = rF;
-    partials[2 * blockIdx.x + 1] = rL;
-  }
+  const double r[2] = {block_sum(accF, lds), block_sum(accL, lds)};
+  grid_finish<2>(r, scratch, out_dev, out_host, lds, sig);
 }
 
 
@@ -195,7 +236,8 @@ __global__ __launch_bounds__(kBlock) void trial_f0_kernel(int n, int N, BarrierP
                                                            const double* __restrict__ Dz0, double* Dz,
                                                            const double* __restrict__ w, const double* __restrict__ c,
                                                            const double* __restrict__ phi_ref, double frac,
-                                                           double* __restrict__ phi_out, double* partials) {
+                                                           double* __restrict__ phi_out, double* scratch, double* out_dev,
+                                                           double* out_host, HostSignal sig) {
   __shared__ double lds[kBlock / 64];
   __shared__ double dzs[kTrialNodes * kMaxK];
   constexpr int GR = kBlock / G;      // rows per pass
@@ -265,12 +307,8 @@ __global__ __launch_bounds__(kBlock) void trial_f0_kernel(int n, int N, BarrierP
     }
     __syncthreads();
   }
-  double rF = block_sum(accF, lds);
-  double rL = block_sum(accL, lds);
-  if (threadIdx.x == 0) {
-    partials[2 * blockIdx.x] = rF;
-    partials[2 * blockIdx.x + 1] = rL;
-  }
+  const double r[2] = {block_sum(accF, lds), block_sum(accL, lds)};
+  grid_finish<2>(r, scratch, out_dev, out_host, lds, sig);
 }
 
 inline int trial_grid(int n) {
@@ -281,9 +319,10 @@ inline int trial_grid(int n) {
 template <int G>
 void trial_launch(hipStream_t st, const DevCsr& B, int n, const BarrierParams& P, const double* s, double alpha,
                   const double* nstep, double* s_out, const double* Dz0, double* Dz, const double* w, const double* c,
-                  const double* phi_ref, double frac, double* phi_out, double* partials) {
+                  const double* phi_ref, double frac, double* phi_out, double* scratch, double* out_dev, double* out_host,
+                  HostSignal sig) {
   hipLaunchKernelGGL(trial_f0_kernel<G>, dim3(trial_grid(n)), dim3(kBlock), 0, st, n, B.cols, P, B.rowptr, B.colidx, B.vals, s,
-                     alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials);
+                     alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, scratch, out_dev, out_host, sig);
 }
 
 // register-only helpers: the D-row indices of a cone are run-time data, so rows are picked / updated with
@@ -379,22 +418,32 @@ __global__ __launch_bounds__(kBlock) void col_extract_kernel(int n, int K, int k
     out[i] = M[i * K + k];
 }
 
+// flag_dev / flag_host (nullable): the pivot flag of the factorisation that produced y -- all its launches precede this
+// one on the stream -- is handed to the host next to the dot product and re-armed (zeroed) for the next factorisation, so the
+// Newton loop needs neither a memset nor a copy launch for it.
 __global__ __launch_bounds__(kBlock) void dot_kernel(int n, const double* __restrict__ x, const double* __restrict__ y,
-                                                      double* partials) {
+                                                      double* scratch, double* out_dev, double* out_host, int* flag_dev,
+                                                      int* flag_host, HostSignal sig) {
   __shared__ double lds[kBlock / 64];
+  if (flag_dev && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int f = __hip_atomic_load(flag_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(flag_host, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(flag_dev, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   double acc = 0.0;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
     acc += x[i] * y[i];
-  double r = block_sum(acc, lds);
-  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+  const double r[1] = {block_sum(acc, lds)};
+  grid_finish<1>(r, scratch, out_dev, out_host, lds, sig);
 }
 
-__global__ __launch_bounds__(kBlock) void sum_kernel(int n, const double* __restrict__ x, double* partials) {
+__global__ __launch_bounds__(kBlock) void sum_kernel(int n, const double* __restrict__ x, double* scratch, double* out_dev,
+                                                      double* out_host) {
   __shared__ double lds[kBlock / 64];
   double acc = 0.0;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) acc += x[i];
-  double r = block_sum(acc, lds);
-  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+  const double r[1] = {block_sum(acc, lds)};
+  grid_finish<1>(r, scratch, out_dev, out_host, lds);
 }
 
 __global__ __launch_bounds__(kBlock) void isfinite_kernel(int n, const double* __restrict__ x, int* flag) {
@@ -428,25 +477,26 @@ int f0_blocks(int n) { return std::max(grid_for(n), trial_grid(n)); }
 
 void launch_trial_f0(hipStream_t st, const DevCsr& B, int n, BarrierParams P, const double* s, double alpha,
                      const double* nstep, double* s_out, const double* Dz0, double* Dz, const double* w, const double* c,
-                     const double* phi_ref, double frac, double* phi_out, double* partials, double* out2) {
+                     const double* phi_ref, double frac, double* phi_out, double* scratch, double* out2, double* out2_host,
+                     HostSignal sig) {
+#define MGB_TRIAL(G) trial_launch<G>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, scratch, out2, out2_host, sig)
   switch (B.group) {
-    case 1: trial_launch<1>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials); break;
-    case 2: trial_launch<2>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials); break;
-    case 4: trial_launch<4>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials); break;
-    case 8: trial_launch<8>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials); break;
-    case 16: trial_launch<16>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials); break;
-    case 32: trial_launch<32>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials); break;
-    default: trial_launch<64>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, partials); break;
+    case 1: MGB_TRIAL(1); break;
+    case 2: MGB_TRIAL(2); break;
+    case 4: MGB_TRIAL(4); break;
+    case 8: MGB_TRIAL(8); break;
+    case 16: MGB_TRIAL(16); break;
+    case 32: MGB_TRIAL(32); break;
+    default: MGB_TRIAL(64); break;
   }
-  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, trial_grid(n), 2, partials, out2);
+#undef MGB_TRIAL
 }
 
 void launch_barrier_f0(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
-                       const double* phi_ref, double frac, double* phi_out, double* partials, double* out2) {
-  const int grid = grid_for(n);
-  hipLaunchKernelGGL(barrier_f0_kernel, dim3(grid), dim3(kBlock), 0, st, n, P, Dz, w, c, phi_ref, frac, phi_out,
-                     partials);
-  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, grid, 2, partials, out2);
+                       const double* phi_ref, double frac, double* phi_out, double* scratch, double* out2, double* out2_host,
+                       HostSignal sig) {
+  hipLaunchKernelGGL(barrier_f0_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, P, Dz, w, c, phi_ref, frac, phi_out, scratch,
+                     out2, out2_host, sig);
 }
 
 void launch_barrier_f1(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
@@ -458,16 +508,13 @@ void launch_barrier_f2(hipStream_t st, int n, BarrierParams P, const double* Dz,
   hipLaunchKernelGGL(barrier_f2_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, P, Dz, w, Y);
 }
 
-void launch_dot(hipStream_t st, int n, const double* x, const double* y, double* partials, double* out) {
-  const int grid = grid_for(n);
-  hipLaunchKernelGGL(dot_kernel, dim3(grid), dim3(kBlock), 0, st, n, x, y, partials);
-  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, grid, 1, partials, out);
+void launch_dot(hipStream_t st, int n, const double* x, const double* y, double* scratch, double* out, double* out_host,
+                int* flag_dev, int* flag_host, HostSignal sig) {
+  hipLaunchKernelGGL(dot_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, x, y, scratch, out, out_host, flag_dev, flag_host, sig);
 }
 
-void launch_sum(hipStream_t st, int n, const double* x, double* partials, double* out) {
-  const int grid = grid_for(n);
-  hipLaunchKernelGGL(sum_kernel, dim3(grid), dim3(kBlock), 0, st, n, x, partials);
-  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, grid, 1, partials, out);
+void launch_sum(hipStream_t st, int n, const double* x, double* scratch, double* out, double* out_host) {
+  hipLaunchKernelGGL(sum_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, x, scratch, out, out_host);
 }
 
 void launch_all_isfinite(hipStream_t st, int n, const double* x, int* flag) {

@@ -47,28 +47,44 @@ struct BarrierParams {
 void launch_spmv(hipStream_t st, const DevCsr& A, const double* x, const double* y0, double* y);
 // out = x + alpha*y
 void launch_waxpby(hipStream_t st, int n, const double* x, double alpha, const double* y, double* out);
+// Reductions finish inside the producing launch (csrc/kernels.hip: grid_finish): `scratch` starts with
+// kReductionHeader doubles of ticket words -- ZERO before the first launch, re-armed by every launch -- followed by the
+// per-block partials (2 * f0_blocks(n) doubles for the objective kernels, f0_blocks(n) for dot / sum).  Results go to `out` (device, for a
+// following collective) and / or `out_host` (pinned host memory the kernel writes directly: no copy launch); either may be null.
 // out2[0] = sum_q w F(Dz_q) ; out2[1] = sum_q w <c_q, Dz_q>   (+inf / NaN if any row infeasible)
-// partials: scratch of 2*f0_blocks(n) doubles.
+constexpr int kReductionHeader = 144;      // 9 ticket counters x 128 bytes
+// Completion signal of a reduction launch (nullable pair): after the results are in `out_host`, the launch bumps the device
+// counter *seq_dev and stores the new value to pinned host memory *seq_host (system-scope release).  A host that polls
+// *seq_host learns of the result ~1 us after the kernel, without the 15-25 us of an interrupt-driven stream synchronisation.
+struct HostSignal {
+  unsigned long long* seq_dev = nullptr;
+  unsigned long long* seq_host = nullptr;
+};
 int f0_blocks(int n);
 // phi_ref (nullable, n x ncones) + frac: fraction-to-the-boundary test of a line-search trial; phi_out
 // (nullable, n x ncones): per-row cone distances s^(2/p) - |q|^2 of this evaluation.
 void launch_barrier_f0(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
-                       const double* phi_ref, double frac, double* phi_out, double* partials, double* out2);
+                       const double* phi_ref, double frac, double* phi_out, double* scratch, double* out2,
+                       double* out2_host = nullptr, HostSignal sig = HostSignal());
 // the same two sums for x = s + alpha * nstep (nstep nullable: x = s) in one launch: Dz = Dz0 + B x is written on the
 // way (B: the n K x N apply_D matrix of the level, rows node-major), s_out (nullable) receives x
 void launch_trial_f0(hipStream_t st, const DevCsr& B, int n, BarrierParams P, const double* s, double alpha,
                      const double* nstep, double* s_out, const double* Dz0, double* Dz, const double* w, const double* c,
-                     const double* phi_ref, double frac, double* phi_out, double* partials, double* out2);
+                     const double* phi_ref, double frac, double* phi_out, double* scratch, double* out2,
+                     double* out2_host = nullptr, HostSignal sig = HostSignal());
 // v[q,k] = w_q (dF/dDz_k + t c[q,k])
 void launch_barrier_f1(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
                        double t, double* v);
 // Y[q, base_c + slot(a,b)] = w_q d2F/dDz_a dDz_b over cone c's active columns (a<=b),
 // slot = a*nact - a(a-1)/2 + (b-a)
 void launch_barrier_f2(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, double* Y);
-// out[0] = sum x_i y_i ; partials scratch of f0_blocks(n) doubles
-void launch_dot(hipStream_t st, int n, const double* x, const double* y, double* partials, double* out);
-// out[0] = sum x_i ; partials scratch of f0_blocks(n) doubles
-void launch_sum(hipStream_t st, int n, const double* x, double* partials, double* out);
+// out[0] = sum x_i y_i ; scratch of kReductionHeader + f0_blocks(n) doubles
+// flag_dev / flag_host (nullable pair): *flag_host = *flag_dev, then *flag_dev = 0 (a device flag set by EARLIER launches on the
+// stream travels to pinned host memory with the dot product and is re-armed)
+void launch_dot(hipStream_t st, int n, const double* x, const double* y, double* scratch, double* out, double* out_host = nullptr,
+                int* flag_dev = nullptr, int* flag_host = nullptr, HostSignal sig = HostSignal());
+// out[0] = sum x_i ; scratch of kReductionHeader + f0_blocks(n) doubles
+void launch_sum(hipStream_t st, int n, const double* x, double* scratch, double* out, double* out_host = nullptr);
 // flag[0] = 1 if all finite else 0
 void launch_all_isfinite(hipStream_t st, int n, const double* x, int* flag);
 // out = x .* y
