@@ -320,3 +320,20 @@ def test_status_codes_come_from_exception_types(lib):
     rc = lib.mgb_geo_set_matrix(h, b"op:id", 2, 2, rp.ctypes.data_as(ip), ci.ctypes.data_as(ip), va.ctypes.data_as(dp))
     assert rc == -1 and b"CSR" in lib.mgb_last_error()
     assert lib.mgb_geo_destroy(h) == 0
+
+
+def test_julia_shim_binds_only_declared_entry_points(lib):
+    """julia/MultiGridBarrierHIP.jl cannot be executed here (no Julia toolchain): at least every C symbol it binds must be
+    declared in include/mgb_hip.h and exported by the library, it must define the ten hooks of src:62 and `solve`, and stay
+    within the size SURVEY.md section 7.1 step 9 asks for."""
+    src = open(os.path.join(ROOT, "julia", "MultiGridBarrierHIP.jl")).read()
+    used = set(re.findall(r"(?:@mgb\s+|:\s*|\(:)(mgb_[a-z0-9_]+)", src))
+    hdr = open(os.path.join(ROOT, "include", "mgb_hip.h")).read()
+    declared = set(re.findall(r"\b(mgb_[A-Za-z0-9_]+)\s*\(", hdr))
+    assert len(used) >= 30 and used <= declared, sorted(used - declared)
+    for name in used:
+        assert hasattr(lib, name)
+    for hook in ("amgb_zeros", "amgb_all_isfinite", "amgb_diag", "amgb_blockdiag", "map_rows", "map_rows_gpu", "vertex_indices",
+                 "_raw_array", "_to_cpu_array", "_rows_to_svectors", "MultiGridBarrier.solve", "native_to_hip", "hip_to_native"):
+        assert re.search(r"^\s*(function\s+)?%s\(" % re.escape(hook), src, re.M), hook
+    assert len(src.splitlines()) <= 320
