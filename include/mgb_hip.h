@@ -121,6 +121,15 @@ int mgb_amg_create(mgb_ctx ctx, mgb_geo g, int S, const char* const* state_vars,
 int mgb_amg_create_cones(mgb_ctx ctx, mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D,
                          int ncones, const int* nq, const int* idx_q, const int* idx_s, const int* idx_s2,
                          const double* p, mgb_amg* out);
+/* General barrier menu: an intersection of 1 to 3 convex sets (upstream `intersect`), term c being
+ *   kind[c] = 0: the power cone above (nq[c], idx_q[3c + i], idx_s[c], idx_s2[c] (nullable array), p[c]);
+ *   kind[c] = 1: the half space  sum_i coef[3c + i] * Dz[:, idx_q[3c + i]] + off[c] > 0,  i < nq[c] <= 3  (upstream
+ *                convex_linear with one constant row: bounds and constant obstacles), barrier -log of the affine form;
+ *                idx_s[c], p[c] ignored.
+ * coef / off may be NULL when every term is a power cone. */
+int mgb_amg_create_terms(mgb_ctx ctx, mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D,
+                         int nterms, const int* kind, const int* nq, const int* idx_q, const int* idx_s, const int* idx_s2,
+                         const double* p, const double* coef, const double* off, mgb_amg* out);
 int mgb_amg_destroy(mgb_amg a);
 int mgb_amg_dims(mgb_amg a, int* n, int* S, int* K, int* L, int* nY);   /* n = LOCAL rows on a sharded context */
 int mgb_amg_local_rows(mgb_amg a, int* n_global, int* row0, int* n_local);

@@ -595,8 +595,10 @@ class AMG:
 
     def __init__(self, geometry: Geometry, state_variables=DEFAULT_STATE, D=None, p: float = 1.0, idx=None,
                  cones=None):
-        """`cones` = [(idx, p) | (idx, p, idx_s2), ...] selects an intersection of up to two power cones
-        (idx = D rows of (q_1..q_d, s)); default: one cone on the last dim+1 rows of D with exponent p."""
+        """`cones` = the terms of the barrier (an intersection of up to three convex sets, upstream `intersect`):
+        (idx, p) | (idx, p, idx_s2) -- the power cone s >= |q|^p on the D rows idx = (q_1..q_d, s) (convex_Euclidian_power);
+        ("linear", idx, coef, off)  -- the half space sum_i coef[i] * Dz[:, idx[i]] + off > 0 (convex_linear with one constant
+        row: bounds, constant obstacles).  Default: one power cone on the last dim+1 rows of D with exponent p."""
         if geometry._geo is None:
             raise TypeError("AMG needs an MPI geometry (use native_to_mpi / fem*d_mpi)")
         dim = geometry.discretization["dim"]
@@ -608,17 +610,27 @@ class AMG:
             cones = [(list(idx), float(p))]
         self.geometry = geometry
         self.state_variables, self.D, self.p, self.cones = tuple(state_variables), tuple(D), float(p), list(cones)
-        self.idx = list(cones[0][0])
+        power = [c for c in cones if c[0] != "linear"]
+        self.idx = list(power[0][0]) if power else []
         backend = geometry.x.backend
         nc = len(cones)
-        nq = (C.c_int * nc)(*[len(c[0]) - 1 for c in cones])
-        iq = (C.c_int * (3 * nc))(*sum([(list(c[0][:-1]) + [0, 0, 0])[:3] for c in cones], []))
-        isl = (C.c_int * nc)(*[int(c[0][-1]) for c in cones])
-        is2 = (C.c_int * nc)(*[int(c[2]) if len(c) > 2 else -1 for c in cones])
-        pp = (C.c_double * nc)(*[float(c[1]) for c in cones])
+        kind, nq, iq, isl, is2, pp, coef, off = [], [], [], [], [], [], [], []
+        for c in cones:
+            if c[0] == "linear":
+                _, cidx, ccoef, coff = c
+                if not 1 <= len(cidx) <= 3 or len(ccoef) != len(cidx):
+                    raise ValueError("linear barrier term: 1..3 columns with one coefficient each")
+                kind.append(1); nq.append(len(cidx)); iq += (list(cidx) + [0, 0, 0])[:3]; isl.append(0); is2.append(-1)
+                pp.append(1.0); coef += (list(map(float, ccoef)) + [0.0, 0.0, 0.0])[:3]; off.append(float(coff))
+            else:
+                kind.append(0); nq.append(len(c[0]) - 1); iq += (list(c[0][:-1]) + [0, 0, 0])[:3]; isl.append(int(c[0][-1]))
+                is2.append(int(c[2]) if len(c) > 2 else -1); pp.append(float(c[1])); coef += [0.0, 0.0, 0.0]; off.append(0.0)
+        arr_i = lambda v: (C.c_int * len(v))(*v)
+        arr_d = lambda v: (C.c_double * len(v))(*v)
         h = C.c_void_p()
-        call("mgb_amg_create_cones", backend.handle, geometry._geo, len(state_variables),
-             _lib.str_array(state_variables), K, _lib.str_array(D), nc, nq, iq, isl, is2, pp, C.byref(h))
+        call("mgb_amg_create_terms", backend.handle, geometry._geo, len(state_variables), _lib.str_array(state_variables), K,
+             _lib.str_array(D), nc, arr_i(kind), arr_i(nq), arr_i(iq), arr_i(isl), arr_i(is2), arr_d(pp), arr_d(coef), arr_d(off),
+             C.byref(h))
         self.handle = h
         n, S, K_, L, nY = (C.c_int() for _ in range(5))
         call("mgb_amg_dims", h, C.byref(n), C.byref(S), C.byref(K_), C.byref(L), C.byref(nY))
@@ -778,8 +790,8 @@ class AMG:
             pass
 
 
-def amg(geometry: Geometry, state_variables=DEFAULT_STATE, D=None, p=1.0) -> AMG:
-    return AMG(geometry, state_variables, D, p)
+def amg(geometry: Geometry, state_variables=DEFAULT_STATE, D=None, p=1.0, cones=None) -> AMG:
+    return AMG(geometry, state_variables, D, p, cones=cones)
 
 
 @dataclass
@@ -793,16 +805,17 @@ class AMGBSOL:
 
 
 def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=None, g=None, tol=None, t=0.1,
-         maxit=10000, kappa=10.0, verbose=False, logfile=None, schedule="fine", solver="gpu", **rest) -> AMGBSOL:
+         maxit=10000, kappa=10.0, verbose=False, logfile=None, schedule="fine", solver="gpu", cones=None, **rest) -> AMGBSOL:
     """MultiGridBarrier.amgb on an MPI geometry (called at src:599,666).  kwargs as documented in
     docs/src/guide.md:148-152; unknown kwargs (e.g. `L`, forwarded by fem*d_mpi_solve, src:663-666)
-    are ignored like Julia's `kwargs...` fan-out."""
+    are ignored like Julia's `kwargs...` fan-out.  `cones` (upstream kwarg `Q`: the convex set) selects the barrier terms,
+    see `AMG`; default = the p-Laplace power cone."""
     if geometry._geo is None:
         raise TypeError("amgb: geometry must come from native_to_mpi / fem*d_mpi")
     dim = geometry.discretization["dim"]
     f = DEFAULT_F[dim] if f is None else f
     g = DEFAULT_G[dim] if g is None else g
-    M = AMG(geometry, state_variables, D, p)
+    M = AMG(geometry, state_variables, D, p, cones=cones)
     x = geometry.x.to_numpy()
     z0 = np.vstack([np.asarray(g(xi), dtype=np.float64) for xi in x])        # g_grid (n, S)
     c = np.vstack([np.asarray(f(xi), dtype=np.float64) for xi in x])         # f_grid (n, K)
@@ -816,6 +829,8 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
         # the slack row is `id` of a :full state variable (that space contains the constants), so a constant
         # shift sigma = 1 + max(|q|^p - s) of that variable is strictly feasible.  Dz comes from the device.
         idx = M.idx
+        if not idx or len(M.cones) != 1:
+            raise MGBError(-3, "amgb: infeasible start (the closed-form feasibility phase covers a single power cone only)")
         var, op = M.D[idx[-1]]
         names = [sv[0] for sv in M.state_variables]
         if op != "id" or dict(M.state_variables)[var] != "full":

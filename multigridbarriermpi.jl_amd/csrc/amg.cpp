@@ -293,10 +293,11 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
   if (const char* e = std::getenv("MGB_FUSED_TRIAL_ROWS")) fused_trial_rows_ = std::atoi(e);      // 0: never fuse
   if (P.K != (int)spec.D.size()) throw ArgError("amg: barrier K != number of D rows");
-  if (P.ncones < 1 || P.ncones > 2) throw ArgError("amg: barrier supports 1 or 2 cones");
+  if (P.ncones < 1 || P.ncones > kMaxCones) throw ArgError("amg: barrier supports 1 to 3 terms");
   if (P.K > 8) throw ArgError("amg: the barrier kernels support at most 8 rows of D");
   for (int ci = 0; ci < P.ncones; ++ci) {
     const ConeSpec& S = P.cone[ci];
+    if (S.kind != 0 && S.kind != 1) throw ArgError("amg: unknown barrier term kind");
     if (S.nq < 1 || S.nq > 3) throw ArgError("amg: barrier supports 1..3 gradient components");
     for (int a = 0; a < S.nact(); ++a)
       if (S.col(a) < 0 || S.col(a) >= P.K) throw ArgError("amg: barrier index out of range");
@@ -783,6 +784,12 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
       double phi = INFINITY, sv = INFINITY;
       for (int ci = 0; ci < P_.ncones; ++ci) {
         const ConeSpec& S = P_.cone[ci];
+        if (S.kind == 1) {
+          double ph = S.off;
+          for (int i = 0; i < S.nq; ++i) ph += S.coef[i] * d[S.iq[i]];
+          phi = std::min(phi, ph);
+          continue;
+        }
         double qq = 0;
         for (int i = 0; i < S.nq; ++i) qq += d[S.iq[i]] * d[S.iq[i]];
         const double sc = d[S.is] + (S.is2 >= 0 ? d[S.is2] : 0.0);

@@ -173,6 +173,46 @@ BarrierParams make_params_cones(int K, int ncones, const int* nq, const int* idx
   return P;
 }
 
+// general menu: term c is a power cone (kind 0: nq, idx_q, idx_s, idx_s2, p as above) or a half space (kind 1: columns
+// idx_q[3c .. 3c + nq), coefficients coef[3c ..], constant offset off[c]; idx_s / p ignored)
+BarrierParams make_params_terms(int K, int nterms, const int* kind, const int* nq, const int* idx_q, const int* idx_s,
+                                const int* idx_s2, const double* p, const double* coef, const double* off) {
+  need(nterms >= 1 && nterms <= kMaxCones && kind && nq && idx_q, "barrier: 1 to 3 terms expected");
+  BarrierParams P;
+  P.K = K;
+  P.ncones = nterms;
+  for (int c = 0; c < nterms; ++c) {
+    if (kind[c] == 0) {
+      need(idx_s && p, "barrier: power cone needs idx_s and p");
+      const int is2 = idx_s2 ? idx_s2[c] : -1;
+      BarrierParams one = make_params_cones(K, 1, nq + c, idx_q + 3 * c, idx_s + c, &is2, p + c);
+      P.cone[c] = one.cone[0];
+    } else {
+      need(kind[c] == 1, "barrier: unknown term kind");
+      need(coef && off && nq[c] >= 1 && nq[c] <= 3, "barrier: half space needs 1..3 columns, coef and off");
+      ConeSpec& S = P.cone[c];
+      S.kind = 1;
+      S.nq = nq[c];
+      bool any = false;
+      for (int i = 0; i < nq[c]; ++i) {
+        need(idx_q[3 * c + i] >= 0 && idx_q[3 * c + i] < K, "barrier: idx_q out of range");
+        for (int j = 0; j < i; ++j) need(idx_q[3 * c + j] != idx_q[3 * c + i], "barrier: repeated column in a half space");
+        need(std::isfinite(coef[3 * c + i]), "barrier: coefficient not finite");
+        S.iq[i] = idx_q[3 * c + i];
+        S.coef[i] = coef[3 * c + i];
+        any = any || coef[3 * c + i] != 0.0;
+      }
+      need(any && std::isfinite(off[c]), "barrier: half space needs a nonzero coefficient and a finite offset");
+      S.is = S.iq[0];      // unused by kind 1; keep indices in range
+      S.is2 = -1;
+      S.off = off[c];
+      S.a = 1.0;
+      S.mu = 0.0;
+    }
+  }
+  return P;
+}
+
 BarrierParams make_params(int K, int nq, const int* idx_q, int idx_s, double p) {
   need(nq >= 1 && nq <= 3 && idx_q, "barrier: nq must be 1..3");
   int iq3[3] = {0, 0, 0};
@@ -584,6 +624,25 @@ int mgb_amg_create_cones(mgb_ctx ctx, mgb_geo g, int S, const char* const* state
     need(ctx && g && out, "null argument");
     AmgSpec spec = make_spec(S, state_vars, K, D);
     BarrierParams P = make_params_cones(K, ncones, nq, idx_q, idx_s, idx_s2, p);
+    auto* a = new mgb_amg_s{ctx, nullptr, {}};
+    try {
+      const auto t0 = std::chrono::steady_clock::now();
+      a->amg.reset(new Amg(ctx->ctx, g->g, spec, P));
+      a->stats.t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } catch (...) {
+      delete a;
+      throw;
+    }
+    *out = a;
+  });
+}
+int mgb_amg_create_terms(mgb_ctx ctx, mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D, int nterms,
+                         const int* kind, const int* nq, const int* idx_q, const int* idx_s, const int* idx_s2, const double* p,
+                         const double* coef, const double* off, mgb_amg* out) {
+  return guard([&] {
+    need(ctx && g && out, "null argument");
+    AmgSpec spec = make_spec(S, state_vars, K, D);
+    BarrierParams P = make_params_terms(K, nterms, kind, nq, idx_q, idx_s, idx_s2, p, coef, off);
     auto* a = new mgb_amg_s{ctx, nullptr, {}};
     try {
       const auto t0 = std::chrono::steady_clock::now();

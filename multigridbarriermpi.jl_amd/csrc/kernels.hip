@@ -176,6 +176,19 @@ __device__ inline double pow_a(double s, double a) {
 
 __device__ inline Cone load_cone(const ConeSpec& P, const double* dz) {
   Cone c;
+  if (P.kind == 1) {      // half space: phi = coef . y + off, no slack (s = 1 makes the mu log s term vanish)
+    double phi = P.off;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      c.q[i] = (i < P.nq) ? dz[P.iq[i]] : 0.0;
+      phi += (i < P.nq) ? P.coef[i] * c.q[i] : 0.0;
+    }
+    c.s = 1.0;
+    c.sa = 1.0;
+    c.phi = phi;
+    c.ok = phi > 0.0;
+    return c;
+  }
   double qq = 0.0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -344,6 +357,16 @@ __global__ __launch_bounds__(kBlock) void barrier_f1_kernel(int n, BarrierParams
     for (int ci = 0; ci < P.ncones; ++ci) {
       const ConeSpec& S = P.cone[ci];
       Cone k = load_cone(S, dz);
+      if (S.kind == 1) {      // half space: dF/dy_i = -coef_i / phi
+#pragma unroll
+        for (int j = 0; j < kMaxK; ++j) {
+          double add = 0.0;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) add += (i < S.nq && S.iq[i] == j) ? -wq * (S.coef[i] / k.phi) : 0.0;
+          vr[j] += add;
+        }
+        continue;
+      }
       const double ds = S.a * pow_a(k.s, S.a - 1.0);  // d(s^a)/ds
       const double gs = wq * (-ds / k.phi - S.mu / k.s);      // same expressions as the oracle (divisions kept)
 #pragma unroll
@@ -374,6 +397,15 @@ __global__ __launch_bounds__(kBlock) void barrier_f2_kernel(int n, BarrierParams
     for (int ci = 0; ci < P.ncones; ++ci) {
       const ConeSpec& S = P.cone[ci];
       Cone k = load_cone(S, dz);
+      if (S.kind == 1) {      // half space: d2F = coef coef' / phi^2, upper triangle row-major over its columns
+        const double ip2l = 1.0 / (k.phi * k.phi);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            if (i < S.nq && j >= i && j < S.nq) yq[slot++] = wq * (S.coef[i] * S.coef[j] * ip2l);
+        continue;
+      }
       const double a = S.a;
       const double ds = a * pow_a(k.s, a - 1.0);
       const double dds = (a == 1.0) ? 0.0 : a * (a - 1.0) * pow_a(k.s, a - 2.0);

@@ -14,28 +14,35 @@ struct DevCsr {
   double* vals = nullptr;
 };
 
-// One power cone  Q = {(q,s): s >= |q|^p}  with barrier  F = -log(s^(2/p) - |q|^2) - mu log s  acting on
-// columns iq[0..nq) and `is` of the n x K row-major matrix Dz.  If is2 >= 0 the slack is Dz[is] + Dz[is2]
-// (feasibility phase: the extra column relaxes the cone).
+// One term of the barrier, acting on columns of the n x K row-major matrix Dz:
+//   kind 0 -- power cone  Q = {(q,s): s >= |q|^p}  (upstream convex_Euclidian_power), F = -log(s^(2/p) - |q|^2) - mu log s
+//             on columns iq[0..nq) and `is`.  If is2 >= 0 the slack is Dz[is] + Dz[is2] (feasibility phase: the extra column
+//             relaxes the cone).
+//   kind 1 -- half space  {y: sum_i coef[i] y[iq[i]] + off > 0}  (upstream convex_linear with one constant row: bounds and
+//             constant obstacles), F = -log(sum_i coef[i] y[iq[i]] + off); its cone distance phi is that affine form.
 struct ConeSpec {
+  int kind = 0;
   int nq = 0;
   int iq[3] = {0, 0, 0};
   int is = 0;
   int is2 = -1;
   double a = 2.0;   // 2/p
   double mu = 1.0;
-  __host__ __device__ int nact() const { return nq + 1 + (is2 >= 0 ? 1 : 0); }
+  double coef[3] = {0.0, 0.0, 0.0};
+  double off = 0.0;
+  __host__ __device__ int nact() const { return kind == 1 ? nq : nq + 1 + (is2 >= 0 ? 1 : 0); }
   __host__ __device__ int nY() const { return nact() * (nact() + 1) / 2; }
   // active column a (0..nact) -> row of D
   __host__ __device__ int col(int a) const { return a < nq ? iq[a] : (a == nq ? is : is2); }
 };
 
-// Barrier of an intersection of up to two power cones (upstream `convex_Euclidian_power` and its
-// intersection): F = sum of the cone barriers.  Hessian slots: cone 0's (a<=b) pairs, then cone 1's.
+// Barrier of an intersection of up to three such sets (upstream `intersect`): F = sum of the terms' barriers.
+// Hessian slots: term 0's (a<=b) pairs, then term 1's, ...
+constexpr int kMaxCones = 3;
 struct BarrierParams {
   int K = 0;
   int ncones = 1;
-  ConeSpec cone[2];
+  ConeSpec cone[kMaxCones];
   __host__ __device__ int nY() const {
     int s = 0;
     for (int c = 0; c < ncones; ++c) s += cone[c].nY();

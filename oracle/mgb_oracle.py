@@ -509,6 +509,39 @@ def convex_Euclidian_power(idx, p) -> PowerConeBarrier:
 
 
 @dataclass
+class LinearBarrier:
+    """Half space {y: sum_i coef[i] y[idx[i]] + off > 0} (upstream `convex_linear` with one constant row: bounds, constant
+    obstacles): F = -log(coef . y[idx] + off); the cone distance phi of the line search is that affine form."""
+    idx: Sequence[int]
+    coef: Sequence[float]
+    off: float
+
+    def phi(self, Y):
+        return Y[:, list(self.idx)] @ np.asarray(self.coef, dtype=np.float64) + self.off
+
+    def F(self, x, Y):
+        phi = self.phi(Y)
+        with np.errstate(all="ignore"):
+            return np.where(phi > 0, -np.log(phi), np.inf)
+
+    def F1(self, x, Y):
+        G = np.zeros_like(Y)
+        phi = self.phi(Y)
+        for i, ci in zip(self.idx, self.coef):
+            G[:, i] = -ci / phi
+        return G
+
+    def F2(self, x, Y):
+        n, K = Y.shape
+        H = np.zeros((n, K, K))
+        phi = self.phi(Y)
+        for i, ci in zip(self.idx, self.coef):
+            for j, cj in zip(self.idx, self.coef):
+                H[:, i, j] = ci * cj / phi ** 2
+        return H
+
+
+@dataclass
 class ConeIntersection:
     """Intersection of power cones acting on disjoint column sets of Dz (upstream `intersect` of
     convex sets, used by parabolic_solve): the barrier is the sum of the cone barriers."""
@@ -783,7 +816,8 @@ class AMGBSOL:
 
 def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=None, g=None,
          tol=None, t=0.1, maxit=10000, kappa=10.0, verbose=False, logfile=None, keep_log=False,
-         schedule=None) -> AMGBSOL:
+         schedule=None, extra=()) -> AMGBSOL:
+    """`extra`: further convex sets intersected with the p-Laplace power cone (upstream `intersect`), e.g. LinearBarrier."""
     dim = geometry.discretization["dim"]
     f = DEFAULT_F[dim] if f is None else f
     g = DEFAULT_G[dim] if g is None else g
@@ -794,11 +828,13 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
     c = map_rows(lambda xi: f(xi), x)            # (n, K)
     nD = len(M.D)
     Q = convex_Euclidian_power(idx=list(range(1, dim + 2)) if nD == dim + 2 else list(range(nD - dim - 1, nD)), p=p)
-    B = Barrier(Q)
+    B = Barrier(ConeIntersection([Q, *extra]) if extra else Q)
     zvec = z0.reshape(-1, order="F")
     Dz = B.apply_D(M.D, zvec)
     log = [] if keep_log else None
     SOL_feas = None
+    if extra and not np.all(np.isfinite(B.Q.F(x, Dz))):
+        raise RuntimeError("amgb: infeasible start (the closed-form feasibility phase covers a single power cone only)")
     if not np.all(np.isfinite(Q.F(x, Dz))):
         zvec, SOL_feas = amgb_phase1(geometry, state_variables, M.Dspec, Q, zvec, Dz, tol, schedule)
     SOL = amgb_core(B, M, zvec, c, tol, t=t, maxit=maxit, kappa=kappa, log=log, schedule=schedule)

@@ -258,6 +258,59 @@ def test_fraction_to_boundary_trial_matches_oracle(M):
     assert seen == {True, False}                                  # the sweep crosses the rule
 
 
+# ---------------------------------------------------------------- barrier menu: power cone intersected with a half space
+OBST_G = {2: lambda x: np.array([0.3 + 0.5 * (x[0] ** 2 + x[1] ** 2), 100.0]), 1: lambda x: np.array([0.3 + 0.5 * x[0] ** 2, 100.0])}
+OBST_F = {2: lambda x: np.array([5.0, 0.0, 0.0, 1.0]), 1: lambda x: np.array([5.0, 0.0, 1.0])}
+
+
+@pytest.mark.parametrize("kind,L,p,psi", [("fem2d", 3, 1.0, 0.1), ("fem2d", 3, 2.0, 0.2), ("fem1d", 4, 1.5, 0.1)])
+def test_obstacle_barrier_matches_oracle(M, kind, L, p, psi):
+    """General barrier menu: the p-Laplace power cone intersected with the half space u - psi > 0 (upstream
+    `intersect(convex_Euclidian_power, convex_linear)`: a constant lower obstacle).  With the load f = (5, 0.., 1) the
+    unconstrained minimiser dips below psi (for p = 1 it is unbounded below), so the obstacle is active.  Kernel level (f0,
+    f1, f2 at a random point) at 1e-12 / 1e-11 and the whole solve at 1e-10 against the oracle."""
+    dim = 1 if kind == "fem1d" else 2
+    gm = getattr(M, kind + "_mpi")(L)
+    go = getattr(O, kind)(L)
+    cone = (list(range(1, dim + 2)), p)
+    lin = ("linear", [0], [1.0], -psi)
+    A = M.AMG(gm, p=p, cones=[cone, lin])
+    assert A.nY == (dim + 1) * (dim + 2) // 2 + 1
+    Mo = O.amg(go)
+    z0 = O.map_rows(lambda xi: OBST_G[dim](xi), Mo.x).reshape(-1, order="F")
+    c = O.map_rows(lambda xi: OBST_F[dim](xi), Mo.x)
+    A.set_c(c)
+    A.set_z(z0)
+    Bo = O.Barrier(O.ConeIntersection([O.convex_Euclidian_power(list(range(1, dim + 2)), p), O.LinearBarrier([0], [1.0], -psi)]))
+    l = L - 1
+    Ro = Mo.R[l]
+    Rg = sp.block_diag([gm.subspaces["dirichlet"][l].host, gm.subspaces["full"][l].host], format="csr")
+    pi = _match_columns(Ro, Rg)
+    N = Ro.shape[1]
+    rng = np.random.default_rng(3)
+    so = 2e-3 * rng.standard_normal(N)
+    sg = np.zeros(N)
+    sg[pi] = so
+    t = 2.5
+    y_o = Bo.f0(so, Mo.x, Mo.w, t * c, Ro, Mo.D, z0)
+    assert np.isfinite(y_o) and abs(A.f0(l, sg, t) - y_o) <= KTOL * abs(y_o)
+    assert rel(A.f1(l, sg, t)[pi], Bo.f1(so, Mo.x, Mo.w, t * c, Ro, Mo.D, z0)) < 1e-11
+    H_o = Bo.f2(so, Mo.x, Mo.w, t * c, Ro, Mo.D, z0).toarray()
+    H_g = A.f2(l, sg, t)[0].toarray()[np.ix_(pi, pi)]
+    assert np.abs(H_g - H_o).max() <= 1e-11 * np.abs(H_o).max()
+    # a trial that crosses the obstacle is reported as infeasible, not raised
+    sbad = np.zeros(N)
+    sbad[: Rg.shape[1] // 3] = -10.0
+    assert not np.isfinite(A.f0(l, sbad, t))
+    sol = M.amgb(gm, p=p, f=OBST_F[dim], g=OBST_G[dim], cones=[cone, lin])
+    ref = O.amgb(go, p=p, f=OBST_F[dim], g=OBST_G[dim], extra=[O.LinearBarrier([0], [1.0], -psi)])
+    z = M.mpi_to_native(sol).z
+    assert rel(z, ref.z) < ZTOL
+    assert z[:, 0].min() > psi and z[:, 0].min() - psi < 1e-3            # strictly feasible, and the obstacle is active
+    with pytest.raises(M.MGBError):                                          # bad term descriptions are argument errors
+        M.AMG(gm, p=p, cones=[cone, ("linear", [0, 0], [1.0, 1.0], 0.0)])
+
+
 # ---------------------------------------------------------------- whole solves
 CASES = [("fem1d", 3, 1.0), ("fem1d", 4, 2.0), ("fem2d", 2, 1.5), ("fem2d", 3, 1.0), ("fem2d", 3, 2.0),
          ("fem3d", 2, 1.0), ("fem3d", 2, 2.0)]
@@ -288,10 +341,12 @@ def test_solve_matches_oracle_and_golden(M, kind, L, p):
     assert rel(z, zo) < ZTOL
 
 
-@pytest.mark.parametrize("kind,L,p", [("fem1d", 4, 1.0), ("fem2d", 3, 1.5)])
+@pytest.mark.parametrize("kind,L,p", [("fem1d", 4, 1.0), ("fem2d", 3, 1.5), ("fem2d", 5, 1.5)])
 def test_level_loop_schedule_matches_oracle(M, kind, L, p):
     """The literal coarse -> fine level loop (schedule='all', SURVEY §3.1 amgb_step) against the oracle run
-    with the same schedule; it must also land on the same z as the default schedule."""
+    with the same schedule; it must also land on the same z as the default schedule.  fem2d L=5 is a mesh whose
+    fine levels have multi-panel fronts (oracle: 652 Newton steps against 96 with the default schedule,
+    profiles/r2_schedule_newton_counts.txt)."""
     sol = getattr(M, kind + "_mpi_solve")(L=L, p=p, schedule="all")
     z = M.mpi_to_native(sol).z
     so = getattr(O, kind + "_solve")(L=L, p=p, schedule="all")
