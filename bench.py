@@ -192,8 +192,8 @@ def main():
     geo = M.fem2d_mpi(args.L, backend=backend)
     A = M.AMG(geo, p=args.p)
     x = geo.x.to_numpy()
-    z0 = np.vstack([M.DEFAULT_G[2](xi) for xi in x]).reshape(-1, order="F")
-    c = np.vstack([M.DEFAULT_F[2](xi) for xi in x])
+    z0 = M._rows(M.DEFAULT_G[2], x).reshape(-1, order="F")
+    c = M._rows(M.DEFAULT_F[2], x)
     A.set_c(c)
     A.prepare()                  # operators, Hessian plan, factorisation structures: setup, not solve
     backend.synchronize()
@@ -208,8 +208,8 @@ def main():
     # preload code objects with a tiny solve (not a warmup step of the workload)
     small = M.AMG(M.fem2d_mpi(3 if sharded else 2, backend=backend), p=args.p)
     xs = small.geometry.x.to_numpy()
-    small.set_c(np.vstack([M.DEFAULT_F[2](xi) for xi in xs]))
-    small.set_z(np.vstack([M.DEFAULT_G[2](xi) for xi in xs]).reshape(-1, order="F"))
+    small.set_c(M._rows(M.DEFAULT_F[2], xs))
+    small.set_z(M._rows(M.DEFAULT_G[2], xs).reshape(-1, order="F"))
     small.solve()
     del small
 

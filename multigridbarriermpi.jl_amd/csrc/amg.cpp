@@ -4,6 +4,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <thread>
 #include <cstdlib>
 #include <cstdio>
 
@@ -134,6 +135,12 @@ Csr build_dstack(const GeometryHost& g, const AmgSpec& spec) {
 
 LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr& Dstack, int level,
                            const BarrierParams& P) {
+  static const bool vt = std::getenv("MGB_VERBOSE_SETUP") != nullptr;
+  double tph = now_s();
+  auto phase = [&](const char* what) {
+    if (vt) std::fprintf(stderr, "[mgb setup] plan %-22s %.3f s\n", what, now_s() - tph);
+    tph = now_s();
+  };
   LevelPlan pl;
   const int n = g.n, K = P.K;
   std::vector<const Csr*> subs;
@@ -162,6 +169,7 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
         }
       }
   }
+  phase("R, B = D R, B'");
   // Hessian plan: A = sum_q sum_cones sum_{a<=b} Y[q, base_c + slot(a,b)] * (B_a[q,:]' B_b[q,:] + sym), lower
   // triangle only; a, b run over the cone's active D rows (ConeSpec::col)
   const int nY = P.nY();
@@ -195,31 +203,58 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
     return (u.present[(size_t)a * nc + i] && u.present[(size_t)b * nc + j]) ||
            (a != b && u.present[(size_t)b * nc + i] && u.present[(size_t)a * nc + j]);
   };
-  // pass A: pattern
-  std::vector<unsigned long long> keys;
-  keys.reserve((size_t)n * 40);
-  RowU u;
-  for (int q = 0; q < n; ++q) {
-    for (int ci = 0; ci < P.ncones; ++ci) {
-      const ConeSpec& S = P.cone[ci];
-      const int nact = S.nact();
-      gather(q, S, u);
-      const int nc = (int)u.cols.size();
-      for (int i = 0; i < nc; ++i)
-        for (int j = 0; j <= i; ++j) {
-          bool any = false;
-          for (int a = 0; a < nact && !any; ++a)
-            for (int b = a; b < nact && !any; ++b) any = structural(u, nc, a, b, i, j);
-          if (any) keys.push_back(((unsigned long long)u.cols[i] << 32) | (unsigned)u.cols[j]);
-        }
+  // Both passes run over node chunks on the host threads (MfChol::threads(): affinity mask, at most 16); every result is
+  // assembled in node order, so the plan is identical to the sequential one.
+  const int nthr = std::max(1, std::min(MfChol::threads(), n / 2048));
+  auto chunks = [&](auto&& fn) {      // fn(q_lo, q_hi, thread)
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthr; ++t)
+      th.emplace_back([&, t] { fn((int)((long long)n * t / nthr), (int)((long long)n * (t + 1) / nthr), t); });
+    fn(0, (int)((long long)n / nthr), 0);
+    for (auto& x : th) x.join();
+  };
+  // pass A: pattern (lower triangle of R'HR): per chunk sorted + unique keys, then one sort of the (already small) union
+  std::vector<std::vector<unsigned long long>> tkeys(nthr);
+  chunks([&](int q0, int q1, int tI) {
+    std::vector<unsigned long long>& keys = tkeys[tI];
+    keys.reserve((size_t)(q1 - q0) * 40);
+    RowU u;
+    for (int q = q0; q < q1; ++q) {
+      for (int ci = 0; ci < P.ncones; ++ci) {
+        const ConeSpec& S = P.cone[ci];
+        const int nact = S.nact();
+        gather(q, S, u);
+        const int nc = (int)u.cols.size();
+        for (int i = 0; i < nc; ++i)
+          for (int j = 0; j <= i; ++j) {
+            bool any = false;
+            for (int a = 0; a < nact && !any; ++a)
+              for (int b = a; b < nact && !any; ++b) any = structural(u, nc, a, b, i, j);
+            if (any) keys.push_back(((unsigned long long)u.cols[i] << 32) | (unsigned)u.cols[j]);
+          }
+      }
+      if (keys.size() > (size_t)8 << 20) {  // compact periodically
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+      }
     }
-    if (keys.size() > (size_t)64 << 20) {  // compact periodically
-      std::sort(keys.begin(), keys.end());
-      keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  });
+  phase("pattern keys");
+  std::vector<unsigned long long> keys;
+  {
+    size_t tot = 0;
+    for (auto& k : tkeys) tot += k.size();
+    keys.reserve(tot);
+    for (auto& k : tkeys) {
+      keys.insert(keys.end(), k.begin(), k.end());
+      std::vector<unsigned long long>().swap(k);
     }
   }
   std::sort(keys.begin(), keys.end());
   keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  phase("sort / unique");
   pl.Apat = Csr(pl.N, pl.N);
   pl.Apat.colidx.resize(keys.size());
   pl.Apat.vals.assign(keys.size(), 0.0);
@@ -233,27 +268,23 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
     const int* e0 = pl.Apat.colidx.data() + pl.Apat.rowptr[r + 1];
     return (int)(std::lower_bound(b0, e0, c) - pl.Apat.colidx.data());
   };
-  // pass B: count, pass C: fill (terms of one entry end up ordered by q, cone, slot)
+  // pass B: every chunk lists its terms (entry, Y column, coefficient) in node order and counts them per entry; the
+  // terms of one entry then go to T ordered by chunk = by node, cone, slot -- exactly the sequential order
   const int nnzA = pl.Apat.nnz();
   pl.T = Csr(nnzA, n * nY);
-  std::vector<long long> cnt(nnzA + 1, 0);
-  for (int pass = 0; pass < 2; ++pass) {
-    std::vector<long long> pos;
-    if (pass == 1) {
-      long long tot = 0;
-      for (int e = 0; e < nnzA; ++e) {
-        long long c0 = cnt[e];
-        cnt[e] = tot;
-        tot += c0;
-      }
-      cnt[nnzA] = tot;
-      if (tot > 2000000000LL) throw ArgError("amg: Hessian plan exceeds Int32 indexing");
-      for (int e = 0; e <= nnzA; ++e) pl.T.rowptr[e] = (int)cnt[e];
-      pl.T.colidx.resize((size_t)tot);
-      pl.T.vals.resize((size_t)tot);
-      pos.assign(cnt.begin(), cnt.end() - 1);
-    }
-    for (int q = 0; q < n; ++q) {
+  struct Term {
+    int e, col;
+    double coef;
+  };
+  std::vector<std::vector<Term>> tterms(nthr);
+  std::vector<std::vector<int>> tcnt(nthr);
+  chunks([&](int q0, int q1, int tI) {
+    std::vector<Term>& terms = tterms[tI];
+    std::vector<int>& cnt = tcnt[tI];
+    cnt.assign(nnzA, 0);
+    terms.reserve((size_t)(q1 - q0) * 80);
+    RowU u;
+    for (int q = q0; q < q1; ++q) {
       int base = 0;
       for (int ci = 0; ci < P.ncones; ++ci) {
         const ConeSpec& S = P.cone[ci];
@@ -268,21 +299,42 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
               for (int b = a; b < nact; ++b, ++slot) {
                 if (!structural(u, nc, a, b, i, j)) continue;
                 if (e < 0) e = entry(u.cols[i], u.cols[j]);
-                if (pass == 0) {
-                  cnt[e]++;
-                } else {
-                  double coef = u.val[(size_t)a * nc + i] * u.val[(size_t)b * nc + j];
-                  if (a != b) coef += u.val[(size_t)b * nc + i] * u.val[(size_t)a * nc + j];
-                  const long long pp = pos[e]++;
-                  pl.T.colidx[pp] = q * nY + slot;
-                  pl.T.vals[pp] = coef;
-                }
+                double coef = u.val[(size_t)a * nc + i] * u.val[(size_t)b * nc + j];
+                if (a != b) coef += u.val[(size_t)b * nc + i] * u.val[(size_t)a * nc + j];
+                terms.push_back({e, q * nY + slot, coef});
+                cnt[e]++;
               }
           }
         base += S.nY();
       }
     }
+  });
+  phase("list terms");
+  {
+    long long tot = 0;
+    for (int e = 0; e < nnzA; ++e) {
+      pl.T.rowptr[e] = (int)tot;
+      for (int t = 0; t < nthr; ++t) {
+        const int c0 = tcnt[t][e];
+        tcnt[t][e] = (int)tot;      // becomes this chunk's first position inside entry e
+        tot += c0;
+      }
+      if (tot > 2000000000LL) throw ArgError("amg: Hessian plan exceeds Int32 indexing");
+    }
+    pl.T.rowptr[nnzA] = (int)tot;
+    pl.T.colidx.resize((size_t)tot);
+    pl.T.vals.resize((size_t)tot);
   }
+  chunks([&](int, int, int tI) {
+    std::vector<int>& pos = tcnt[tI];
+    for (const Term& tm : tterms[tI]) {
+      const int pp = pos[tm.e]++;
+      pl.T.colidx[pp] = tm.col;
+      pl.T.vals[pp] = tm.coef;
+    }
+    std::vector<Term>().swap(tterms[tI]);
+  });
+  phase("fill terms");
   return pl;
 }
 
@@ -371,6 +423,7 @@ Amg::Level& Amg::level(int l) {
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
   lv.plan = build_level_plan(geo_, spec_, dstack_host_, l, P_);
   if (ctx_.world > 1) lv.plan = shard_level_plan(lv.plan, ng_, S_, P_.K, P_.nY(), r0_, r0_ + n_);
+  const double t_up = now_s();
   lv.R.upload(lv.plan.R);
   lv.B.upload(lv.plan.B);
   lv.BT.upload(lv.plan.BT);
@@ -387,6 +440,7 @@ Amg::Level& Amg::level(int l) {
   lv.h_g.alloc(N);
   lv.h_n.alloc(N);
   lv.h_s.alloc(N);
+  if (std::getenv("MGB_VERBOSE_SETUP")) std::fprintf(stderr, "[mgb setup] level upload + buffers       %.3f s\n", now_s() - t_up);
   lv.built = true;
   return lv;
 }
@@ -396,8 +450,13 @@ Amg::Level& Amg::level(int l) {
 void Amg::ensure_chol(Level& lv) {
   if (lv.chol_built) return;
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
+  static const bool vt = std::getenv("MGB_VERBOSE_SETUP") != nullptr;
+  double t0 = now_s();
   lv.chol.analyze(lv.plan.Apat, lv.plan.coords.data(), geo_.dim);
+  if (vt) std::fprintf(stderr, "[mgb setup] chol analyze                %.3f s\n", now_s() - t0);
+  t0 = now_s();
   lv.gchol.build(lv.chol, &ctx_);      // sharded context: split by subtrees (gpuchol.hpp)
+  if (vt) std::fprintf(stderr, "[mgb setup] gpuchol build + upload      %.3f s\n", now_s() - t0);
   lv.chol_built = true;
 }
 

@@ -36,10 +36,26 @@ void ck(hipError_t e, const char* what) {
 }
 
 // optional phase stamps (100 MHz wall clock) of workgroup 0 of every factorisation launch: MGB_CHOL_PROF=1
+// slots 0..7: phase stamps of workgroup 0.  With -DMGB_PROF_ALL_WGS (a debugging build: the atomics cost registers in every
+// kernel) slot 8 / 9 also record the earliest STAMP(0) / latest STAMP(7) over ALL workgroups of the launch and which
+// workgroup finished last -- how the off-diagonal tiles were found to bound a panel step (profiles/r2_chol_phase_stamps_L7.txt).
+constexpr int kProfSlots = 10;
+#ifdef MGB_PROF_ALL_WGS
+#define STAMP(k)                                                                                   \
+  do {                                                                                             \
+    if (prof && threadIdx.x == 0) {                                                                \
+      const long long now_ = wall_clock64();                                                       \
+      if (blockIdx.x == 0) prof[k] = now_;                                                         \
+      if ((k) == 0) atomicMin((unsigned long long*)&prof[8], (unsigned long long)now_);            \
+      if ((k) == 7) atomicMax((unsigned long long*)&prof[9], (unsigned long long)now_ * 65536ull + (blockIdx.x & 65535u)); \
+    }                                                                                              \
+  } while (0)
+#else
 #define STAMP(k)                                                                   \
   do {                                                                             \
     if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[k] = wall_clock64();     \
   } while (0)
+#endif
 
 // broadcast lane `lane` (compile-time constant) of a double through SGPRs
 __device__ inline double readlane_f64(double v, int lane) {
@@ -287,6 +303,74 @@ __device__ inline void trsm_row(double (&f)[PB], const double* Lc, int kw = PB) 
   }
 }
 
+// The same substitution with FOUR lanes per row (a quad: lanes 4 r .. 4 r + 3 of a wave, lane c4 owning the entries
+// m = c4, c4 + 4, .. of the row in f[0..8)): the 496 multiply-adds of a row are split four ways and the solved entry
+// x_j travels from its owner to the other three lanes with a quad-broadcast DPP move (one VALU pass, no LDS), so a wave
+// solves 16 rows and all four waves of a workgroup work -- with one lane per row a wave spent ~3 us on its 64 rows while
+// two or three waves idled.  Operation order per entry is that of trsm_row: bitwise the same result.
+// Lq: the pivot block in "quad" order, Lq[32 j + 8 (m & 3) + (m >> 2)] = L[m][j] (reciprocal diagonal), so that the
+// entries of column j a lane needs are contiguous (b128 LDS reads).
+__device__ __forceinline__ int lq_index(int m, int j) { return 32 * j + 8 * (m & 3) + (m >> 2); }
+
+template <int OWNER>
+__device__ __forceinline__ double quad_bcast(double v) {
+  constexpr int ctrl = OWNER * 0x55;      // quad_perm: every lane of the quad reads lane OWNER
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <int J>
+__device__ __forceinline__ void trsm_quad_load(double (&col)[PB / 4], double& diag, const double* Lq, int c4) {
+  if constexpr (J < PB) {
+#pragma unroll
+    for (int k = J >> 2; k < PB / 4; ++k) col[k] = Lq[32 * J + 8 * c4 + k];      // this lane's entries of column J: L[c4 + 4 k][J]
+    diag = Lq[32 * J + 8 * (J & 3) + (J >> 2)];                                   // 1 / L[J][J]
+  }
+}
+
+// software pipeline: the entries of column J + 2 are requested before column J is consumed (two columns in flight cover
+// the LDS latency of the short steps); the empty asm keeps the compiler from hoisting ALL columns (it did: 372 VGPRs)
+// or sinking the loads next to their uses
+template <int J, bool EXIT>
+__device__ __forceinline__ void trsm_quad_step(double (&f)[PB / 4], const double* Lq, int c4, int kw, const double (&col)[PB / 4],
+                                               double diag, const double (&col1)[PB / 4], double diag1) {
+  if constexpr (J < PB) {
+    constexpr int owner = J & 3, kk = J >> 2;
+    if (EXIT && (J & 7) == 0 && J >= kw) return;      // identity padding (workgroup-uniform)
+    double col2[PB / 4], diag2 = 0.0;
+    trsm_quad_load<J + 2>(col2, diag2, Lq, c4);
+    asm volatile("" ::: "memory");
+    const double fj = quad_bcast<owner>(f[kk] * diag);
+    const double lkk = (c4 > owner) ? col[kk] : 0.0;     // entries of this lane left of / on the diagonal: no update
+    f[kk] = (c4 == owner) ? fj : fma(-fj, lkk, f[kk]);
+#pragma unroll
+    for (int k = kk + 1; k < PB / 4; ++k) f[k] = fma(-fj, col[k], f[k]);
+    trsm_quad_step<J + 1, EXIT>(f, Lq, c4, kw, col1, diag1, col2, diag2);
+  }
+}
+
+template <bool EXIT = false>
+__device__ __forceinline__ void trsm_quad(double (&f)[PB / 4], const double* Lq, int c4, int kw = PB) {
+  double col[PB / 4], diag = 0.0, col1[PB / 4], diag1 = 0.0;
+  trsm_quad_load<0>(col, diag, Lq, c4);
+  trsm_quad_load<1>(col1, diag1, Lq, c4);
+  trsm_quad_step<0, EXIT>(f, Lq, c4, kw, col, diag, col1, diag1);
+}
+
+// X L11' = A for the 64 rows of a staged panel block AT (AT[q * TP + r] = (row r, panel column q)), in place, by all four
+// waves: wave w takes rows 16 w .. 16 w + 15, four lanes per row.
+template <bool EXIT = false>
+__device__ __forceinline__ void trsm_block64(double* AT, int TP, const double* Lq, int kw = PB) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = 16 * w + (lane >> 2), c4 = lane & 3;
+  double f[PB / 4];
+#pragma unroll
+  for (int k = 0; k < PB / 4; ++k) f[k] = AT[(c4 + 4 * k) * TP + r];
+  trsm_quad<EXIT>(f, Lq, c4, kw);
+#pragma unroll
+  for (int k = 0; k < PB / 4; ++k) AT[(c4 + 4 * k) * TP + r] = f[k];
+}
+
 // the same substitution straight from the row-major PACKED factor Lo (broadcast reads do not care about the
 // stride) with a one-column register window: front_leaf_kernel trades the last LDS latency for occupancy
 __device__ inline void trsm_row_lo(double (&f)[PB], const double* Lo, int kw) {
@@ -328,7 +412,7 @@ __device__ inline void pivot_path(const StepTile& t, int p, double* sh, double* 
   const int nf = t.nf, ld = nf + 1, k0 = p * PB, kw = min(PB, t.ns - k0), k1 = k0 + kw, kw2 = min(PB, t.ns - k1);
   double* F = fronts + t.off;
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < PB * PB; idx += TB) Lc[idx] = linv_ro[t.loff + PB * PB + idx];
+  for (int idx = tid; idx < PB * PB; idx += TB) Lc[lq_index(idx % PB, idx / PB)] = linv_ro[t.loff + PB * PB + idx];      // quad order
   // the corner as three 16x16 blocks of the lower triangle, one per wave (wave 3 idles), in the result layout of
   // v_mfma_f64_16x16x4_f64 with m = corner column, n = corner row: lane (li, lk) holds (row 16 bi + li, column
   // 16 bj + lk + 4 reg), so the loads run along the rows of the front
@@ -344,17 +428,22 @@ __device__ inline void pivot_path(const StepTile& t, int p, double* sh, double* 
       acc[reg] = (j <= ci && ci < kw2) ? F[(long long)ld * (k1 + j) + k1 + ci] : 0.0;
     }
   }
-  double f[PB];
-  if (tid < PB) {
+  // the 32 panel rows below the pivot block: waves 0 and 1, 16 rows each, four lanes per row (trsm_quad)
+  const int pr = 16 * w + (lane >> 2), c4 = lane & 3;
+  double f[PB / 4];
+  if (w < 2) {
 #pragma unroll
-    for (int m = 0; m < PB; ++m) f[m] = (m < kw && tid < kw2) ? F[(long long)ld * (k0 + m) + k1 + tid] : 0.0;
+    for (int k = 0; k < PB / 4; ++k) {
+      const int m = c4 + 4 * k;
+      f[k] = (m < kw && pr < kw2) ? F[(long long)ld * (k0 + m) + k1 + pr] : 0.0;
+    }
   }
   __syncthreads();
   STAMP(1);
-  if (tid < PB) {
-    trsm_row(f, Lc);
+  if (w < 2) {      // wave-uniform
+    trsm_quad(f, Lc, c4);
 #pragma unroll
-    for (int m = 0; m < PB; ++m) P[tid * LP + m] = f[m];
+    for (int k = 0; k < PB / 4; ++k) P[pr * LP + c4 + 4 * k] = f[k];
   }
   __syncthreads();
   STAMP(2);
@@ -396,45 +485,17 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   const int r0 = k1 + TS * t.ti, c0 = k1 + TS * t.tj;
   const bool diag = (t.ti == t.tj);
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < PB * PB; idx += TB) Lc[idx] = linv_ro[t.loff + PB * PB + idx];
+  for (int idx = tid; idx < PB * PB; idx += TB) Lc[lq_index(idx % PB, idx / PB)] = linv_ro[t.loff + PB * PB + idx];      // quad order
   // panel rows of the tile, transposed and padded: AT[q * TP + r] = (row r, panel column q)
   for (int idx = tid; idx < TS * PB; idx += TB) {
     const int r = idx % TS, q = idx / TS;
     ATI[q * TP + r] = (q < kw && r0 + r <= nf) ? F[(long long)ld * (k0 + q) + r0 + r] : 0.0;
     if (!diag) ATJ[q * TP + r] = (q < kw && c0 + r <= nf) ? F[(long long)ld * (k0 + q) + c0 + r] : 0.0;
   }
-  __syncthreads();
-  STAMP(1);
-  if (tid < 2 * TS && (tid < TS || !diag)) {
-    // thread = one row of I (wave 0) or J (wave 1), in registers: X L11' = A by right-looking substitution;
-    // column j of L11 is contiguous in the column-major copy, read two entries per (broadcast) LDS access
-    const int r = tid & (TS - 1);
-    double* A = ((tid < TS) ? ATI : ATJ) + r;
-    double f[PB];
-#pragma unroll
-    for (int m = 0; m < PB; ++m) f[m] = A[m * TP];
-    trsm_row(f, Lc);
-#pragma unroll
-    for (int m = 0; m < PB; ++m) A[m * TP] = f[m];
-    if (t.tj == 0 && tid < TS && r0 + r <= nf) {         // finished rows of L go to the mirrored (upper) half
-      double* Lrow = F + (long long)ld * (r0 + r) + k0;
-#pragma unroll
-      for (int m = 0; m < PB; ++m)
-        if (m < kw) Lrow[m] = f[m];
-    }
-  }
-  __syncthreads();
-  STAMP(2);
-  // Rank-32 update C[I, J] -= L_I L_J' on the matrix cores: v_mfma_f64_16x16x4_f64, D[m][n] += A[m][k] B[k][n] with
-  // m = tile column (L_J), n = tile row (L_I), so that the lanes of a result register run along the rows of the
-  // front (unit stride in HBM).  Wave w owns tile rows 16 w .. 16 w + 15 and all four 16-column blocks: lane
-  // (li = lane & 15, lk = lane >> 4) holds C[16 w + li][16 bj + lk + 4 reg] in acc[bj][reg]; per k-step of 4 panel
-  // columns it reads ONE L_I entry and four L_J entries from LDS (a quarter of the operand traffic of the 4x4
-  // register micro-tiles).  The 32x32 corner that becomes the next pivot block belongs to the pivot workgroup.
+  // the C tile is requested now, in the MFMA result layout (see below), so that its global latency overlaps the substitution
   const int kc = (t.ti == 0 && t.tj == 0) ? min(t.ns, k1 + PB) : 0;      // rows/columns < kc: the next pivot block
   const int lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
   const int i = r0 + 16 * w + li;
-  typedef double v4f64 __attribute__((ext_vector_type(4)));
   double c[4][4];
 #pragma unroll
   for (int bj = 0; bj < 4; ++bj)
@@ -443,6 +504,26 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       const int j = c0 + 16 * bj + lk + 4 * reg;
       c[bj][reg] = (i <= nf && j < nf && i >= j && !(i < kc && j < kc)) ? F[(long long)ld * j + i] : 0.0;
     }
+  __syncthreads();
+  STAMP(1);
+  // X L11' = A for the rows of I (and of J off the diagonal) by all four waves, four lanes per row (trsm_block64)
+  trsm_block64(ATI, TP, Lc);
+  if (!diag) trsm_block64(ATJ, TP, Lc);
+  __syncthreads();
+  if (t.tj == 0) {      // finished rows of L go to the mirrored (upper) half: row r0 + r, 32 consecutive entries
+    for (int idx = tid; idx < TS * PB; idx += TB) {
+      const int r = idx / PB, m = idx % PB;
+      if (r0 + r <= nf && m < kw) F[(long long)ld * (r0 + r) + k0 + m] = ATI[m * TP + r];
+    }
+  }
+  STAMP(2);
+  // Rank-32 update C[I, J] -= L_I L_J' on the matrix cores: v_mfma_f64_16x16x4_f64, D[m][n] += A[m][k] B[k][n] with
+  // m = tile column (L_J), n = tile row (L_I), so that the lanes of a result register run along the rows of the
+  // front (unit stride in HBM).  Wave w owns tile rows 16 w .. 16 w + 15 and all four 16-column blocks: lane
+  // (li = lane & 15, lk = lane >> 4) holds C[16 w + li][16 bj + lk + 4 reg] in acc[bj][reg]; per k-step of 4 panel
+  // columns it reads ONE L_I entry and four L_J entries from LDS (a quarter of the operand traffic of the 4x4
+  // register micro-tiles).  The 32x32 corner that becomes the next pivot block belongs to the pivot workgroup.
+  typedef double v4f64 __attribute__((ext_vector_type(4)));
   const double* LI = ATI + 16 * w + li + lk * TP;
   const double* LJ = (diag ? ATI : ATJ) + li + lk * TP;
   v4f64 acc[4];      // starts as C; the negated L_I operand makes the matrix core return C - L_I L_J'
@@ -581,26 +662,18 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int q = tid; q < ns; q += TB) ATI[q * TP + nf - r0] += b[perm[t.first + q]];
   __syncthreads();
   factor_diag_block<NARROW>(D, kw, Lo, (t.ti == 0 && t.tj == 0) ? linv + t.loff : nullptr, fail, nullptr);
-  for (int idx = tid; idx < PB * PB; idx += TB) Lc[idx] = Lo[(idx % PB) * LP + idx / PB];     // Lc[32 j + m] = L[m][j]
+  for (int idx = tid; idx < PB * PB; idx += TB) Lc[lq_index(idx % PB, idx / PB)] = Lo[(idx % PB) * LP + idx / PB];     // L[m][j], quad order
   __syncthreads();
   STAMP(2);
-  if (tid < 2 * TS && (tid < TS || !diag)) {
-    const int r = tid & (TS - 1);
-    double* A = ((tid < TS) ? ATI : ATJ) + r;
-    double f[PB];
-#pragma unroll
-    for (int m = 0; m < PB; ++m) f[m] = A[m * TP];
-    trsm_row<NARROW>(f, Lc, kw);
-#pragma unroll
-    for (int m = 0; m < PB; ++m) A[m * TP] = f[m];
-    if (t.tj == 0 && tid < TS && r0 + r <= nf) {
-      double* Lrow = F + (long long)ld * (r0 + r);
-#pragma unroll
-      for (int m = 0; m < PB; ++m)
-        if (m < kw) Lrow[m] = f[m];
+  trsm_block64<NARROW>(ATI, TP, Lc, kw);      // all four waves, four lanes per row (see front_step)
+  if (!diag) trsm_block64<NARROW>(ATJ, TP, Lc, kw);
+  __syncthreads();
+  if (t.tj == 0) {
+    for (int idx = tid; idx < TS * PB; idx += TB) {
+      const int r = idx / PB, m = idx % PB;
+      if (r0 + r <= nf && m < kw) F[(long long)ld * (r0 + r) + m] = ATI[m * TP + r];
     }
   }
-  __syncthreads();
   STAMP(3);
   // rank-32 (rank-8 when NARROW) update on the matrix cores, operand and result layout as in front_step
   typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -1205,9 +1278,13 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
   allocs_.push_back(d_fail_);
   ck(hipMemset(d_fail_, 0, sizeof(int)), "memset");
   if (std::getenv("MGB_CHOL_PROF")) {
-    ck(hipMalloc((void**)&d_prof_, (size_t)8 * launches_ * sizeof(long long)), "hipMalloc prof");
+    ck(hipMalloc((void**)&d_prof_, (size_t)kProfSlots * launches_ * sizeof(long long)), "hipMalloc prof");
     allocs_.push_back(d_prof_);
-    ck(hipMemset(d_prof_, 0, (size_t)8 * launches_ * sizeof(long long)), "memset prof");
+    {
+      std::vector<long long> init((size_t)kProfSlots * launches_, 0LL);
+      for (int q = 0; q < launches_; ++q) init[(size_t)kProfSlots * q + 8] = -1LL;
+      ck(hipMemcpy(d_prof_, init.data(), init.size() * sizeof(long long), hipMemcpyHostToDevice), "init prof");
+    }
   }
   // per device (function attributes do not carry over to another GPU of the same process): set on every build
   ck(hipFuncSetAttribute((const void*)backward_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
@@ -1266,7 +1343,7 @@ void GpuChol::enqueue_forward(hipStream_t st, const std::vector<HeightPlan>& pla
       const size_t lds = ((size_t)(hp.max_nf + 1) * hp.max_nf - (size_t)hp.max_nf * (hp.max_nf - 1) / 2) * sizeof(double);
       hipLaunchKernelGGL(front_leaf_kernel, dim3(hp.nodes.cnt), dim3(TB), lds, st, d_nodes_, d_lists_ + hp.nodes.ofs, d_asm_src_,
                          d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_linv_, d_fail_,
-                         d_prof_ ? d_prof_ + 8 * (nprof++) : nullptr);
+                         d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr);
       if (tm) tm->end(st);
       continue;
     }
@@ -1274,19 +1351,19 @@ void GpuChol::enqueue_forward(hipStream_t st, const std::vector<HeightPlan>& pla
       if (tm) tm->begin(st, KC_CHOL_SINGLE, hp.start_bytes + hp.step_bytes[0]);
       hipLaunchKernelGGL(hp.narrow ? front_single_kernel<true> : front_single_kernel<false>, dim3(hp.single_tiles.cnt), dim3(TB), 0, st, d_singles_ + hp.single_tiles.ofs, d_pinv_,
                          d_asm_src_, d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_fronts_, d_linv_, d_fail_,
-                         d_prof_ ? d_prof_ + 8 * (nprof++) : nullptr);
+                         d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr);
       if (tm) tm->end(st);
       continue;
     }
     if (tm) tm->begin(st, KC_CHOL_START, hp.start_bytes);
     hipLaunchKernelGGL(front_start_kernel, dim3(hp.start.cnt), dim3(TB), 0, st, d_nodes_, d_start_ + hp.start.ofs, d_pinv_,
                        d_asm_src_, d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_fronts_, d_linv_, d_fail_,
-                       d_prof_ ? d_prof_ + 8 * (nprof++) : nullptr);
+                       d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr);
     if (tm) tm->end(st);
     for (size_t p = 0; p < hp.step.size(); ++p) {
       if (tm) tm->begin(st, KC_CHOL_STEP, hp.step_bytes[p]);
       hipLaunchKernelGGL(front_step_kernel, dim3(hp.step[p].cnt), dim3(TB), 0, st, d_tiles_ + hp.step[p].ofs, (int)p,
-                         hp.step_npiv[p], d_fronts_, d_linv_, d_linv_, d_fail_, d_prof_ ? d_prof_ + 8 * (nprof++) : nullptr);
+                         hp.step_npiv[p], d_fronts_, d_linv_, d_linv_, d_fail_, d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr);
       if (tm) tm->end(st);
     }
   }
@@ -1350,16 +1427,24 @@ void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, d
   ck(hipGetLastError(), "factor_solve launches");
   if (d_prof_) {      // debugging aid: phase stamps of workgroup 0 of every factorisation launch, in units of 10 ns
     ck(hipStreamSynchronize(st), "prof sync");
-    std::vector<long long> hprof((size_t)8 * nprof);
+    std::vector<long long> hprof((size_t)kProfSlots * nprof);
     ck(hipMemcpy(hprof.data(), d_prof_, hprof.size() * sizeof(long long), hipMemcpyDeviceToHost), "prof D2H");
     std::fprintf(stderr, "[mgb chol prof] launch: load trsm update store sync Dwrite factor tail (us)\n");
     for (int q = 0; q < nprof; ++q) {
-      const long long* v = hprof.data() + 8 * q;
+      const long long* v = hprof.data() + kProfSlots * q;
       std::fprintf(stderr, "[mgb chol prof] %3d:", q);
       for (int k = 1; k < 8; ++k) std::fprintf(stderr, " %6.2f", (v[k] && v[k - 1]) ? (v[k] - v[k - 1]) * 0.01 : 0.0);
-      std::fprintf(stderr, "\n");
+      // all workgroups: first start -> last end, and the time since the previous launch's last end (launch boundary)
+      const long long* pv = q ? hprof.data() + kProfSlots * (q - 1) : nullptr;
+      const long long end_q = (long long)((unsigned long long)v[9] >> 16), end_p = pv ? (long long)((unsigned long long)pv[9] >> 16) : 0;
+      std::fprintf(stderr, "  | all wgs %6.2f (last: wg %5d)  since prev end %6.2f\n", (end_q - v[8]) * 0.01,
+                   (int)((unsigned long long)v[9] & 65535ull), pv ? (v[8] - end_p) * 0.01 : 0.0);
     }
-    ck(hipMemset(d_prof_, 0, hprof.size() * sizeof(long long)), "prof reset");
+    for (int q = 0; q < nprof; ++q) {
+      std::fill(hprof.begin() + (size_t)kProfSlots * q, hprof.begin() + (size_t)kProfSlots * (q + 1), 0LL);
+      hprof[(size_t)kProfSlots * q + 8] = -1LL;      // all ones: atomicMin target (unsigned)
+    }
+    ck(hipMemcpy(d_prof_, hprof.data(), hprof.size() * sizeof(long long), hipMemcpyHostToDevice), "prof reset");
   }
 }
 

@@ -3,7 +3,10 @@
 #include <sched.h>
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -222,8 +225,16 @@ bool partial_chol(double* F, int nf, int ns, int nthreads) {
 
 int MfChol::threads() { return hw_threads(); }
 
+// Nested dissection of dofs[lo, hi) into `sub` (nodes in postorder, indices local to `sub`; the root is the last node).
+// The two halves touch disjoint dofs (and disjoint entries of `label`), so the top `par_depth` levels of the recursion
+// build their halves concurrently into private subtrees, which are then appended left, right, parent: the same postorder
+// the sequential recursion produces.
 int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const double* coords, int dim, int leaf,
-                  std::vector<int>& label, int& next_label, std::vector<std::vector<int>>& own) {
+                  std::vector<int>& label, std::atomic<int>& next_label, Subtree& sub, int par_depth) {
+  std::vector<Node>& nodes_ = sub.nodes;      // shadows the member: this recursion only ever touches `sub`
+  std::vector<std::vector<int>>& own = sub.own;
+  // (`label` entries of dofs outside [lo, hi) may be rewritten concurrently by a sibling subtree: relaxed atomics; their
+  // tags are unique per split, so they never compare equal to this split's tags)
   const int cnt = hi - lo;
   auto make_leaf = [&] {
     nodes_.emplace_back();
@@ -269,17 +280,17 @@ int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const do
     }
     if (cand.empty()) cand.push_back(mid);
   }
-  const int tagA = next_label++, tagB = next_label++;
+  const int tagA = next_label.fetch_add(2), tagB = tagA + 1;
   int midp = cand[0], best_size = -1;
   bool sep_in_A = true;
   for (int bpos : cand) {
-    for (int i = lo; i < bpos; ++i) label[dofs[i]] = tagA;
-    for (int i = bpos; i < hi; ++i) label[dofs[i]] = tagB;
+    for (int i = lo; i < bpos; ++i) __atomic_store_n(&label[dofs[i]], tagA, __ATOMIC_RELAXED);
+    for (int i = bpos; i < hi; ++i) __atomic_store_n(&label[dofs[i]], tagB, __ATOMIC_RELAXED);
     int sa = 0, sb = 0;
     for (int i = lo; i < hi; ++i) {
       const int v = dofs[i], other = (i < bpos) ? tagB : tagA;
       bool sep = false;
-      for (int k = A.rowptr[v]; k < A.rowptr[v + 1] && !sep; ++k) sep = (label[A.colidx[k]] == other);
+      for (int k = A.rowptr[v]; k < A.rowptr[v + 1] && !sep; ++k) sep = (__atomic_load_n(&label[A.colidx[k]], __ATOMIC_RELAXED) == other);
       if (sep) (i < bpos ? sa : sb)++;
     }
     const int sz = std::min(sa, sb);
@@ -289,8 +300,8 @@ int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const do
       sep_in_A = sa <= sb;
     }
   }
-  for (int i = lo; i < midp; ++i) label[dofs[i]] = tagA;
-  for (int i = midp; i < hi; ++i) label[dofs[i]] = tagB;
+  for (int i = lo; i < midp; ++i) __atomic_store_n(&label[dofs[i]], tagA, __ATOMIC_RELAXED);
+  for (int i = midp; i < hi; ++i) __atomic_store_n(&label[dofs[i]], tagB, __ATOMIC_RELAXED);
   // Ap / Bv: the two halves without the separator S (taken from one side)
   std::vector<int> Ap, Bv, S;
   for (int i = lo; i < hi; ++i) {
@@ -299,7 +310,7 @@ int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const do
     bool sep = false;
     if (inA == sep_in_A) {
       const int other = inA ? tagB : tagA;
-      for (int k = A.rowptr[v]; k < A.rowptr[v + 1] && !sep; ++k) sep = (label[A.colidx[k]] == other);
+      for (int k = A.rowptr[v]; k < A.rowptr[v + 1] && !sep; ++k) sep = (__atomic_load_n(&label[A.colidx[k]], __ATOMIC_RELAXED) == other);
     }
     (sep ? S : (inA ? Ap : Bv)).push_back(v);
   }
@@ -308,8 +319,28 @@ int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const do
   std::copy(Bv.begin(), Bv.end(), dofs.begin() + lo + Ap.size());
   std::copy(S.begin(), S.end(), dofs.begin() + lo + Ap.size() + Bv.size());
   const int a_end = lo + (int)Ap.size(), b_end = a_end + (int)Bv.size();
-  const int cl = build(dofs, lo, a_end, A, coords, dim, leaf, label, next_label, own);
-  const int cr = build(dofs, a_end, b_end, A, coords, dim, leaf, label, next_label, own);
+  int cl, cr;
+  if (par_depth > 0 && cnt > 4096) {
+    Subtree left, right;
+    std::thread worker([&] { build(dofs, lo, a_end, A, coords, dim, leaf, label, next_label, left, par_depth - 1); });
+    build(dofs, a_end, b_end, A, coords, dim, leaf, label, next_label, right, par_depth - 1);
+    worker.join();
+    auto append = [&](Subtree& part) {
+      const int off = (int)nodes_.size();
+      for (Node& nd : part.nodes) {
+        if (nd.parent >= 0) nd.parent += off;
+        for (int& c : nd.children) c += off;
+        nodes_.push_back(std::move(nd));
+      }
+      for (auto& o : part.own) own.push_back(std::move(o));
+      return (int)nodes_.size() - 1;      // the part's root
+    };
+    cl = append(left);
+    cr = append(right);
+  } else {
+    cl = build(dofs, lo, a_end, A, coords, dim, leaf, label, next_label, sub, 0);
+    cr = build(dofs, a_end, b_end, A, coords, dim, leaf, label, next_label, sub, 0);
+  }
   nodes_.emplace_back();
   own.emplace_back(S);
   const int t = (int)nodes_.size() - 1;
@@ -323,25 +354,51 @@ void MfChol::analyze(const Csr& Ain, const double* coords, int dim, int leaf_siz
   if (const char* e = std::getenv("MGB_LEAF")) leaf_size = std::max(8, std::atoi(e));      // tuning knob
   if (Ain.rows != Ain.cols) throw ArgError("MfChol: matrix not square");
   n_ = Ain.rows;
-  // symmetric adjacency (pattern + transpose) for ordering and the symbolic phase
-  Csr A;
+  static const bool vt = std::getenv("MGB_VERBOSE_SETUP") != nullptr;
+  auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tph = tnow();
+  auto phase = [&](const char* what) {
+    if (vt) std::fprintf(stderr, "[mgb setup] analyze %-19s %.3f s\n", what, tnow() - tph);
+    tph = tnow();
+  };
+  // symmetric adjacency (pattern + transpose) for ordering and the symbolic phase: counting pass, fill, per-row sort
+  // (a global sort of the 2 nnz triplets was a third of the analysis)
+  Csr A(n_, n_);
   {
-    std::vector<Triplet> t;
-    t.reserve((size_t)Ain.nnz() * 2);
     for (int r = 0; r < n_; ++r)
       for (int k = Ain.rowptr[r]; k < Ain.rowptr[r + 1]; ++k) {
-        t.push_back({r, Ain.colidx[k], 1.0});
-        if (Ain.colidx[k] != r) t.push_back({Ain.colidx[k], r, 1.0});
+        const int c = Ain.colidx[k];
+        A.rowptr[r + 1]++;
+        if (c != r) A.rowptr[c + 1]++;
       }
-    A = from_triplets(n_, n_, std::move(t), true);
+    for (int r = 0; r < n_; ++r) A.rowptr[r + 1] += A.rowptr[r];
+    A.colidx.resize(A.rowptr[n_]);
+    std::vector<int> pos(A.rowptr.begin(), A.rowptr.end() - 1);
+    for (int r = 0; r < n_; ++r)
+      for (int k = Ain.rowptr[r]; k < Ain.rowptr[r + 1]; ++k) {
+        const int c = Ain.colidx[k];
+        A.colidx[pos[r]++] = c;
+        if (c != r) A.colidx[pos[c]++] = r;
+      }
+    for (int r = 0; r < n_; ++r) {
+      std::sort(A.colidx.begin() + A.rowptr[r], A.colidx.begin() + A.rowptr[r + 1]);
+      // the input holds every unordered pair once, so there is nothing to merge
+    }
+    A.vals.assign(A.colidx.size(), 1.0);
   }
+  phase("adjacency");
   nodes_.clear();
   roots_.clear();
-  std::vector<std::vector<int>> own;
   std::vector<int> dofs(n_), label(n_, -1);
   std::iota(dofs.begin(), dofs.end(), 0);
-  int next_label = 0;
-  if (n_ > 0) roots_.push_back(build(dofs, 0, n_, A, coords, dim, leaf_size, label, next_label, own));
+  std::atomic<int> next_label{0};
+  Subtree whole;
+  int par_depth = 0;
+  while ((1 << par_depth) < hw_threads()) ++par_depth;
+  if (n_ > 0) roots_.push_back(build(dofs, 0, n_, A, coords, dim, leaf_size, label, next_label, whole, par_depth));
+  nodes_ = std::move(whole.nodes);
+  std::vector<std::vector<int>>& own = whole.own;
+  phase("nested dissection");
   // numbering: nodes are already in postorder
   perm_.resize(n_);
   iperm_.resize(n_);
@@ -391,6 +448,7 @@ void MfChol::analyze(const Csr& Ain, const double* coords, int dim, int leaf_siz
     max_front_ = std::max(max_front_, nf);
     for (int k = 0; k < nd.ns; ++k) flops_ += (double)(nf - k) * (nf - k);
   }
+  phase("front index lists");
   auto pos_in = [&](const Node& p, int i) -> int {
     if (i < p.first + p.ns) {
       if (i < p.first) throw InternalError("MfChol: index below front");
@@ -408,6 +466,7 @@ void MfChol::analyze(const Csr& Ain, const double* coords, int dim, int leaf_siz
     else if (!nd.bdry.empty())
       throw InternalError("MfChol: root with boundary");
   }
+  phase("extend-add maps");
   // assembly map
   a_idx_.assign(nodes_.size(), {});
   a_pos_.assign(nodes_.size(), {});
@@ -421,7 +480,10 @@ void MfChol::analyze(const Csr& Ain, const double* coords, int dim, int leaf_siz
       a_idx_[t].push_back(k);
       a_pos_[t].push_back(pos_in(nd, i) + nd.nf() * (j - nd.first));
     }
-  fronts_.assign(total, 0.0);
+  phase("assembly map");
+  // the host fronts (106 MB at fem2d L=7) are only touched by the HOST numeric factorisation: allocated on its first use
+  fronts_total_ = total;
+  std::vector<double>().swap(fronts_);
 }
 
 void MfChol::factor_node(int t, const double* vals, bool& ok) {
@@ -447,6 +509,7 @@ void MfChol::factor_node(int t, const double* vals, bool& ok) {
 
 bool MfChol::factor(const double* vals) {
   if (n_ == 0) return true;
+  if (fronts_.size() != fronts_total_) fronts_.assign(fronts_total_, 0.0);
   bool ok = true;
   const int nt = hw_threads();
   const int nn = (int)nodes_.size();
@@ -569,6 +632,7 @@ bool MfChol::factor_solve_dist(const double* vals, double* b, const CholPartitio
     return ok;
   }
   if ((int)part.owner.size() != nn || rank < 0 || rank >= part.world) throw ArgError("MfChol: partition does not match the tree");
+  if (fronts_.size() != fronts_total_) fronts_.assign(fronts_total_, 0.0);
   bool ok = true;
   std::vector<double> y(n_), y0(n_);
   for (int i = 0; i < n_; ++i) y0[i] = y[i] = b[perm_[i]];

@@ -9,6 +9,7 @@
 // the new values, runs dense partial factorizations up the tree (OpenMP tasks over subtrees) and
 // does the two triangular sweeps.
 #pragma once
+#include <atomic>
 #include <functional>
 #include <vector>
 
@@ -47,7 +48,7 @@ class MfChol {
   CholPartition partition(int world) const;
   int size() const { return n_; }
   static int threads();      // worker threads factor() uses (affinity mask, capped at 16; MGB_NUM_THREADS overrides)
-  size_t front_doubles() const { return fronts_.size(); }
+  size_t front_doubles() const { return fronts_total_; }
   double factor_flops() const { return flops_; }
   int num_nodes() const { return (int)nodes_.size(); }
   int max_front() const { return max_front_; }
@@ -68,8 +69,12 @@ class MfChol {
     size_t off = 0;             // offset of the nf x nf column-major front in fronts_
     int nf() const { return ns + (int)bdry.size(); }
   };
+  struct Subtree {      // a piece of the elimination tree under construction (node indices local to the piece)
+    std::vector<Node> nodes;
+    std::vector<std::vector<int>> own;
+  };
   int build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const double* coords, int dim, int leaf,
-            std::vector<int>& label, int& next_label, std::vector<std::vector<int>>& own);
+            std::vector<int>& label, std::atomic<int>& next_label, Subtree& sub, int par_depth);
   void factor_node(int t, const double* vals, bool& ok);
   void forward_node(int t, double* y) const;
   void backward_node(int t, double* y) const;
@@ -80,7 +85,8 @@ class MfChol {
   std::vector<int> roots_;
   std::vector<std::vector<int>> a_idx_; // per node: indices k into vals ...
   std::vector<std::vector<int>> a_pos_; // ... and their destination inside the front
-  std::vector<double> fronts_;
+  std::vector<double> fronts_;          // host numeric fronts, allocated by the first factor()
+  size_t fronts_total_ = 0;
 };
 
 }  // namespace mgb
