@@ -27,6 +27,18 @@ inline int grid_for(long long work_items) {
   return (int)b;
 }
 
+// XCD-aware block order for the gathering kernels.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8
+// share one, MI355X_MICROARCH.md) and every XCD has its own 4 MiB L2: with the natural order, neighbouring row blocks --
+// which gather the same entries of x -- land on eight different L2s and every one of them fetches those entries again
+// (measured at fem2d L=9: restriction 2.6x, Hessian assembly 2.4x, apply_D 1.3x the algorithmic bytes at the fabric,
+// profiles/r2_probe_L9_pmc_traffic.json).  Remapped, XCD k works through the k-th contiguous eighth of the blocks.
+// Speed only: any placement gives the same result.
+__device__ inline unsigned xcd_block(unsigned b, unsigned nb) {
+  if (nb < 16u) return b;
+  const unsigned per = nb >> 3, main = per << 3;      // blocks beyond a multiple of 8 keep their place
+  return b < main ? (b & 7u) * per + (b >> 3) : b;
+}
+
 // ---------------------------------------------------------------- SpMV
 // G lanes cooperate on one row: lane j reads nonzero j, j+G, ... (coalesced across the group and,
 // because consecutive rows are adjacent in CSR storage, across the 64/G rows of a wave); the
@@ -39,7 +51,8 @@ __global__ __launch_bounds__(kBlock) void spmv_kernel(int rows, const int* __res
                                                        const double* __restrict__ x, const double* y0, double* y) {
   const int lane = threadIdx.x % G;
   const long long stride = (long long)gridDim.x * (kBlock / G);
-  for (long long row0 = (long long)blockIdx.x * (kBlock / G) + threadIdx.x / G; row0 < rows; row0 += kSpmvU * stride) {
+  for (long long row0 = (long long)xcd_block(blockIdx.x, gridDim.x) * (kBlock / G) + threadIdx.x / G; row0 < rows;
+       row0 += kSpmvU * stride) {
     int b[kSpmvU], e[kSpmvU];
     double acc[kSpmvU], base[kSpmvU];
 #pragma unroll
@@ -119,14 +132,15 @@ constexpr int kTicketStride = 32;                     // unsigned words per line
 static_assert(kReductionHeader * sizeof(double) >= 9 * kTicketStride * sizeof(unsigned), "ticket words");
 template <int NOUT>
 __device__ inline void grid_finish(const double (&r)[NOUT] /* valid in thread 0 */, double* scratch, double* out_dev,
-                                   double* out_host, double* lds, HostSignal sig = HostSignal()) {
+                                   double* out_host, double* lds, HostSignal sig = HostSignal(), unsigned slot = 0xffffffffu) {
+  if (slot == 0xffffffffu) slot = blockIdx.x;      // position of this block's partial in the fixed summation order
   __shared__ int is_last;
   unsigned* ticket = reinterpret_cast<unsigned*>(scratch);      // counter k lives at ticket[kTicketStride * k]: a 128-byte line each
   double* partials = scratch + kTicketDoubles;
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int o = 0; o < NOUT; ++o)
-      __hip_atomic_store(&partials[(size_t)blockIdx.x * NOUT + o], r[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&partials[(size_t)slot * NOUT + o], r[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned shard = blockIdx.x & 7u, nshards = gridDim.x < 8u ? gridDim.x : 8u;
     const unsigned in_shard = (gridDim.x - shard + 7u) / 8u;      // blocks with this shard id
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void trial_f0_kernel(int n, int N, BarrierP
   auto xval = [&](int j) { return nstep ? s[j] + alpha * nstep[j] : s[j]; };
   double accF = 0.0, accL = 0.0;
   const int nchunks = (n + kTrialNodes - 1) / kTrialNodes;
-  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+  for (int ch = xcd_block(blockIdx.x, gridDim.x); ch < nchunks; ch += gridDim.x) {
     const int q0 = ch * kTrialNodes, nq = min(kTrialNodes, n - q0), nrows = nq * K;
     const long long r0 = (long long)q0 * K;
     for (int rr0 = grp; rr0 < nrows; rr0 += kSpmvU * GR) {
@@ -321,7 +335,8 @@ __global__ __launch_bounds__(kBlock) void trial_f0_kernel(int n, int N, BarrierP
     __syncthreads();
   }
   const double r[2] = {block_sum(accF, lds), block_sum(accL, lds)};
-  grid_finish<2>(r, scratch, out_dev, out_host, lds, sig);
+  // the partial goes to the slot of the chunk sequence this block worked on, so the sum is the one of the natural order
+  grid_finish<2>(r, scratch, out_dev, out_host, lds, sig, xcd_block(blockIdx.x, gridDim.x));
 }
 
 inline int trial_grid(int n) {
