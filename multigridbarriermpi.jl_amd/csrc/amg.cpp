@@ -753,17 +753,20 @@ bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, do
     KernelTimer* tm = (live_ && timer_.sampling()) ? &timer_ : nullptr;
     const bool flag_rides = ctx_.world == 1;      // the dot kernel behind the chain hands the pivot flag to the host and re-arms it
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (flag_rides && spec && !tm && use_graph && lv.flag_armed) {
+    // `time_factor`: the chain alone (replayed from its own graph, no per-kernel events) between two events on every 8th
+    // step, offset from the per-kernel sampling, scaled by the period
+    const bool time_chain = live_ && timer_.enabled() && (st.n_factor % 8) == 5;
+    if (flag_rides && spec && !tm && !time_chain && use_graph && lv.flag_armed) {
       launch_step_graph(lv, spec);
       st.n_f0 += 2;
     } else {
-      if (tm) {      // the chain's own time, scaled by the sampling period in `time_factor`
+      if (time_chain) {
         hip_check(hipEventCreate(&e0), "event");
         hip_check(hipEventCreate(&e1), "event");
         hip_check(hipEventRecord(e0, ctx_.stream), "record");
       }
       lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g.p, lv.nstep.p, tm, /*flag_armed=*/flag_rides && lv.flag_armed);
-      if (tm) hip_check(hipEventRecord(e1, ctx_.stream), "record");
+      if (time_chain) hip_check(hipEventRecord(e1, ctx_.stream), "record");
       if (flag_rides) {
         launch_dot(ctx_.stream, N, lv.g.p, lv.nstep.p, partials_.p, scal_.p + 3, host_scal(scal_.p + 3), lv.gchol.fail_flag(),
                    h_flag_.p, spec ? HostSignal() : next_signal());
@@ -790,6 +793,7 @@ bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, do
       }
     if (e0) {      // sampled step: stands for the 8 steps of its sampling period
       float ms = 0;
+      hip_check(hipEventSynchronize(e1), "sync chain event");
       if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) st.time_factor += 8.0 * ms * 1e-3;
       (void)hipEventDestroy(e0);
       (void)hipEventDestroy(e1);

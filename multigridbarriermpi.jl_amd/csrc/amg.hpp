@@ -172,6 +172,7 @@ class KernelTimer {
   void enable(bool on) { on_ = on; sampling_ = true; }
   void sample(bool now) { sampling_ = now; }      // gate: only the Newton steps chosen for sampling are timed
   bool sampling() const { return on_ && sampling_; }
+  bool enabled() const { return on_; }
   void begin(hipStream_t st, int cls, double bytes);
   void end(hipStream_t st);
   void collect(SolveStats& st);   // call only after the stream has been synchronised
