@@ -103,6 +103,14 @@ int mgb_norm(mgb_vec x, double* out);                         /* norm(x) (2-norm
 int mgb_sum(mgb_vec x, double* out);                          /* sum(x) tools/profile_barrier.jl:45-59,95-114 */
 /* out[q] = M[q*K + k] of a row-major n x K device matrix: y[:, j] -> HPCVector, test/test_column_extract.jl:50 */
 int mgb_col_extract(mgb_vec M, int n, int K, int k, mgb_vec out);
+/* map_rows / map_rows_gpu (src:161-170) for the closures MultiGridBarrier derives from a convex set -- the only closures the
+ * Newton path ever maps: which = 0: out[q] = F(Dz_q) (n values, +inf outside the set); 1: out = F1 rows (n x K, row-major);
+ * 2: out = F2 rows flattened to K*K columns (n x K*K; column j*K + k, test/test_map_rows_compare.jl:73).  The set is described
+ * as in mgb_amg_create_terms; Dz is an n x K row-major device matrix.  Any other closure has no device form: the host side
+ * evaluates it on a device -> host copy (the reference's _to_cpu_array trade, src:183-188). */
+int mgb_map_rows_barrier(int which, int K, int nterms, const int* kind, const int* nq, const int* idx_q, const int* idx_s,
+                         const int* idx_s2, const double* p, const double* coef, const double* off, int n, mgb_vec Dz,
+                         mgb_vec out);
 int mgb_mul(mgb_vec x, mgb_vec y, mgb_vec out);               /* w .* col, test_column_extract.jl:65 */
 int mgb_axpy(mgb_vec x, double alpha, mgb_vec y, mgb_vec out); /* out = x + alpha*y */
 int mgb_vec_allreduce_sum(mgb_vec x);                         /* sum over the ranks of a sharded context (no-op for world 1); MPI.Allreduce src:125 */

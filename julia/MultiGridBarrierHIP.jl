@@ -190,6 +190,19 @@ function map_rows(f, A::AnyHIP, args...)
     first(rows) isa Number ? HIPVector(Float64.(rows), b) : HIPMatrix(reduce(vcat, (reshape(collect(Float64, r), 1, :) for r in rows)), b)
 end
 map_rows_gpu(f, A::AnyHIP, args...) = map_rows(f, A, args...)
+"F (which = 0), F1 (1) or F2 (2) of an intersection of power cones / half spaces, in the encoding of mgb_amg_create_terms: the
+closures `map_rows` recognises and runs as fused HIP kernels (mgb_map_rows_barrier) instead of the host fallback."
+struct BarrierFn
+    which::Cint; K::Cint
+    kind::Vector{Cint}; nq::Vector{Cint}; idx_q::Vector{Cint}; idx_s::Vector{Cint}; idx_s2::Vector{Cint}
+    p::Vector{Cdouble}; coef::Vector{Cdouble}; off::Vector{Cdouble}
+end
+function map_rows(f::BarrierFn, ::AnyHIP, Dz::HIPMatrix)
+    n, w = size(Dz, 1), (1, f.K, f.K^2)[f.which + 1]
+    out = HIPVector(n * w, Dz.v.backend)
+    @mgb mgb_map_rows_barrier (Cint, Cint, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Handle, Handle) f.which f.K length(f.kind) f.kind f.nq f.idx_q f.idx_s f.idx_s2 f.p f.coef f.off n Dz.v.h out.h
+    f.which == 0 ? out : HIPMatrix(out, (n, w))
+end
 
 # MultiGridBarrier.solve(A, b) = A \ b (test/test_instrumented_solve.jl:25-28,99): the level's fixed-pattern device
 # Cholesky lives behind an AMG handle (mgb_amg_solve_linear_gpu); a bare HIPSparseMatrix is solved on the host.

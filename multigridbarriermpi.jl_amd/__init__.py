@@ -35,7 +35,7 @@ __all__ = [
     "fem3d_mpi_solve", "parabolic_solve", "ParabolicSOL", "native_to_mpi",
     "mpi_to_native", "amgb", "Geometry", "AMGBSOL", "HPCVector", "HPCMatrix", "HPCSparseMatrix",
     "backend_hip", "amgb_zeros", "amgb_all_isfinite", "amgb_diag", "amgb_blockdiag", "map_rows", "map_rows_gpu",
-    "_raw_array", "_to_cpu_array", "MGBError", "device_count", "AMG", "amg", "hcat",
+    "_raw_array", "_to_cpu_array", "MGBError", "device_count", "AMG", "amg", "hcat", "BarrierFn", "barrier_functions",
 ]
 
 
@@ -481,6 +481,8 @@ def map_rows(f: Callable, A, *args):
     on the host on a device->host copy (the same trade as the reference's `_to_cpu_array`, src:183-188)
     and the result is uploaded.  The barrier family used on the Newton hot path never goes through
     here: its F/F1/F2 are the fused HIP kernels behind `AMG.f0/f1/f2`."""
+    if isinstance(f, BarrierFn) and len(args) == 1 and isinstance(args[0], HPCMatrix):
+        return f.rows(args[0])                      # the barrier family: fused HIP kernels, nothing leaves the device
     arrays = [A, *args]
     backend = next((a.backend for a in arrays if hasattr(a, "backend")), None)
     host = [np.asarray(_to_cpu_array(a), dtype=np.float64) for a in arrays]
@@ -709,6 +711,57 @@ DEFAULT_G = {1: _RowFn(lambda x: np.array([x[0], 2.0]), lambda x: np.column_stac
                        lambda x: np.column_stack([x[:, 0] ** 2 + x[:, 1] ** 2 + x[:, 2] ** 2, np.full(x.shape[0], 100.0)]))}   # src:738
 
 
+def _encode_terms(cones):
+    """ctypes arrays describing barrier terms for mgb_amg_create_terms / mgb_map_rows_barrier."""
+    kind, nq, iq, isl, is2, pp, coef, off = [], [], [], [], [], [], [], []
+    for c in cones:
+        if c[0] == "linear":
+            _, cidx, ccoef, coff = c
+            if not 1 <= len(cidx) <= 3 or len(ccoef) != len(cidx):
+                raise ValueError("linear barrier term: 1..3 columns with one coefficient each")
+            kind.append(1); nq.append(len(cidx)); iq += (list(cidx) + [0, 0, 0])[:3]; isl.append(0); is2.append(-1)
+            pp.append(1.0); coef += (list(map(float, ccoef)) + [0.0, 0.0, 0.0])[:3]; off.append(float(coff))
+        else:
+            kind.append(0); nq.append(len(c[0]) - 1); iq += (list(c[0][:-1]) + [0, 0, 0])[:3]; isl.append(int(c[0][-1]))
+            is2.append(int(c[2]) if len(c) > 2 else -1); pp.append(float(c[1])); coef += [0.0, 0.0, 0.0]; off.append(0.0)
+    arr_i = lambda v: (C.c_int * len(v))(*v)
+    arr_d = lambda v: (C.c_double * len(v))(*v)
+    return (len(cones), arr_i(kind), arr_i(nq), arr_i(iq), arr_i(isl), arr_i(is2), arr_d(pp), arr_d(coef), arr_d(off))
+
+
+class BarrierFn:
+    """One of the three row functions MultiGridBarrier derives from a convex set -- F (which = 0), its gradient F1 (1) or its
+    Hessian F2 (2, flattened to K*K columns) -- as an object `map_rows` recognises: `map_rows(fn, x, Dz)` with a device
+    matrix Dz then runs the fused HIP kernels (mgb_map_rows_barrier) instead of the host fallback.  This is the closure
+    pattern-match of SURVEY.md section 7.2-5: the barrier family has a device form, everything else is evaluated on the host.
+    Calling the object on one row (`fn(x_i, dz_i)`, the reference's signature, test/test_apply_d.jl:64,81) works too."""
+
+    def __init__(self, cones, K: int, which: int):
+        self.cones, self.K, self.which = list(cones), int(K), int(which)
+
+    def rows(self, Dz: "HPCMatrix"):
+        n, K = Dz.shape
+        if K != self.K:
+            raise ValueError("BarrierFn: Dz has %d columns, the barrier was built for %d" % (K, self.K))
+        width = (1, K, K * K)[self.which]
+        out = HPCVector(n * width, Dz.backend)
+        call("mgb_map_rows_barrier", self.which, K, *_encode_terms(self.cones), n, Dz._v.handle, out.handle)
+        if self.which == 0:
+            return out
+        M_ = HPCMatrix.__new__(HPCMatrix)
+        M_.shape, M_.backend, M_._v = (n, width), Dz.backend, out
+        return M_
+
+    def __call__(self, x_row, dz_row):
+        r = self.rows(HPCMatrix(np.asarray(dz_row, dtype=np.float64).reshape(1, -1))).to_numpy()
+        return float(r[0]) if self.which == 0 else r[0]
+
+
+def barrier_functions(cones, K: int):
+    """(F, F1, F2) of the intersection of the given terms (see `AMG` for the term syntax), acting on rows of an n x K Dz."""
+    return tuple(BarrierFn(cones, K, w) for w in (0, 1, 2))
+
+
 class AMG:
     """AMG hierarchy + barrier problem resident in HBM (upstream `amg` + `barrier`)."""
 
@@ -732,24 +785,9 @@ class AMG:
         power = [c for c in cones if c[0] != "linear"]
         self.idx = list(power[0][0]) if power else []
         backend = geometry.x.backend
-        nc = len(cones)
-        kind, nq, iq, isl, is2, pp, coef, off = [], [], [], [], [], [], [], []
-        for c in cones:
-            if c[0] == "linear":
-                _, cidx, ccoef, coff = c
-                if not 1 <= len(cidx) <= 3 or len(ccoef) != len(cidx):
-                    raise ValueError("linear barrier term: 1..3 columns with one coefficient each")
-                kind.append(1); nq.append(len(cidx)); iq += (list(cidx) + [0, 0, 0])[:3]; isl.append(0); is2.append(-1)
-                pp.append(1.0); coef += (list(map(float, ccoef)) + [0.0, 0.0, 0.0])[:3]; off.append(float(coff))
-            else:
-                kind.append(0); nq.append(len(c[0]) - 1); iq += (list(c[0][:-1]) + [0, 0, 0])[:3]; isl.append(int(c[0][-1]))
-                is2.append(int(c[2]) if len(c) > 2 else -1); pp.append(float(c[1])); coef += [0.0, 0.0, 0.0]; off.append(0.0)
-        arr_i = lambda v: (C.c_int * len(v))(*v)
-        arr_d = lambda v: (C.c_double * len(v))(*v)
         h = C.c_void_p()
         call("mgb_amg_create_terms", backend.handle, geometry._geo, len(state_variables), _lib.str_array(state_variables), K,
-             _lib.str_array(D), nc, arr_i(kind), arr_i(nq), arr_i(iq), arr_i(isl), arr_i(is2), arr_d(pp), arr_d(coef), arr_d(off),
-             C.byref(h))
+             _lib.str_array(D), *_encode_terms(cones), C.byref(h))
         self.handle = h
         n, S, K_, L, nY = (C.c_int() for _ in range(5))
         call("mgb_amg_dims", h, C.byref(n), C.byref(S), C.byref(K_), C.byref(L), C.byref(nY))

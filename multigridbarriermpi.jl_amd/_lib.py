@@ -64,6 +64,8 @@ PROTOTYPES = {
     "mgb_norm": [H, c_dbl_p],
     "mgb_sum": [H, c_dbl_p],
     "mgb_col_extract": [H, C.c_int, C.c_int, C.c_int, H],
+    "mgb_map_rows_barrier": [C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p,
+                             C.c_int, H, H],
     "mgb_mul": [H, H, H],
     "mgb_axpy": [H, C.c_double, H, H],
     "mgb_vec_allreduce_sum": [H],

@@ -566,6 +566,40 @@ int mgb_col_extract(mgb_vec M, int n, int K, int k, mgb_vec out) {
     hip_check(hipGetLastError(), "col_extract launch");
   });
 }
+int mgb_map_rows_barrier(int which, int K, int nterms, const int* kind, const int* nq, const int* idx_q, const int* idx_s,
+                         const int* idx_s2, const double* p, const double* coef, const double* off, int n, mgb_vec Dz,
+                         mgb_vec out) {
+  return guard([&] {
+    need(Dz && out && n >= 0 && K >= 1 && K <= 8 && which >= 0 && which <= 2, "map_rows_barrier: bad arguments");
+    BarrierParams P = make_params_terms(K, nterms, kind, nq, idx_q, idx_s, idx_s2, p, coef, off);
+    const long long want = which == 0 ? n : (which == 1 ? (long long)n * K : (long long)n * K * K);
+    need((long long)n * K == Dz->n && out->n == want, "map_rows_barrier: shape mismatch");
+    hipStream_t st = Dz->ctx->ctx.stream;
+    hip_check(hipSetDevice(Dz->ctx->ctx.device), "hipSetDevice");
+    if (which == 0) {
+      launch_barrier_rows_F(st, n, P, Dz->buf.p, out->buf.p);
+    } else {
+      // the fused kernels of the Newton path with unit weights: F1 = barrier_f1(w = 1, c = 0), F2 = barrier_f2(w = 1)
+      std::vector<double> ones((size_t)std::max(n, 1), 1.0);
+      DevBuf<double> w;
+      w.upload(ones.data(), ones.size());
+      if (which == 1) {
+        DevBuf<double> c;
+        c.alloc((size_t)std::max(n, 1) * K);
+        hip_check(hipMemsetAsync(c.p, 0, c.n * sizeof(double), st), "memset");
+        if (n) launch_barrier_f1(st, n, P, Dz->buf.p, w.p, c.p, 0.0, out->buf.p);
+        hip_check(hipStreamSynchronize(st), "sync");      // c, w die with this scope
+      } else {
+        DevBuf<double> Y;
+        Y.alloc((size_t)std::max(n, 1) * P.nY());
+        if (n) launch_barrier_f2(st, n, P, Dz->buf.p, w.p, Y.p);
+        launch_expand_hessian_rows(st, n, P, Y.p, out->buf.p);
+        hip_check(hipStreamSynchronize(st), "sync");
+      }
+    }
+    hip_check(hipGetLastError(), "map_rows_barrier launch");
+  });
+}
 int mgb_mul(mgb_vec x, mgb_vec y, mgb_vec out) {
   return guard([&] {
     need(x && y && out && x->n == y->n && x->n == out->n, "mul: shape mismatch");

@@ -446,6 +446,43 @@ __global__ __launch_bounds__(kBlock) void barrier_f2_kernel(int n, BarrierParams
   }
 }
 
+// map_rows of the barrier itself (src:161-170 for the closures MultiGridBarrier builds from a convex set): F per row, and the
+// per-row Hessian in the reference's flattened K x K shape (column (j-1) K + k, test/test_map_rows_compare.jl:73) expanded
+// from the packed slots of barrier_f2_kernel.
+__global__ __launch_bounds__(kBlock) void barrier_rows_F_kernel(int n, BarrierParams P, const double* __restrict__ Dz,
+                                                                 double* __restrict__ out) {
+  for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < n; q += (long long)gridDim.x * kBlock) {
+    const double* dz = Dz + q * P.K;
+    double F = 0.0;
+    for (int ci = 0; ci < P.ncones; ++ci) {
+      Cone k = load_cone(P.cone[ci], dz);
+      F += k.ok ? (-log(k.phi) - P.cone[ci].mu * log(k.s)) : INFINITY;
+    }
+    out[q] = F;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void expand_hessian_rows_kernel(int n, BarrierParams P, const double* __restrict__ Y,
+                                                                      double* __restrict__ out) {
+  const int K = P.K, nY = P.nY();
+  for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < n; q += (long long)gridDim.x * kBlock) {
+    double* o = out + q * K * K;
+    for (int e = 0; e < K * K; ++e) o[e] = 0.0;
+    const double* yq = Y + q * nY;
+    int slot = 0;
+    for (int ci = 0; ci < P.ncones; ++ci) {
+      const ConeSpec& S = P.cone[ci];
+      const int nact = S.nact();
+      for (int a = 0; a < nact; ++a)
+        for (int b = a; b < nact; ++b, ++slot) {
+          const int ra = S.col(a), rb = S.col(b);
+          o[ra * K + rb] += yq[slot];
+          if (ra != rb) o[rb * K + ra] += yq[slot];
+        }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- vector ops
 __global__ __launch_bounds__(kBlock) void waxpby_kernel(int n, const double* __restrict__ x, double alpha,
                                                          const double* __restrict__ y, double* out) {
@@ -553,6 +590,16 @@ void launch_barrier_f1(hipStream_t st, int n, BarrierParams P, const double* Dz,
 
 void launch_barrier_f2(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, double* Y) {
   hipLaunchKernelGGL(barrier_f2_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, P, Dz, w, Y);
+}
+
+void launch_barrier_rows_F(hipStream_t st, int n, BarrierParams P, const double* Dz, double* out) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(barrier_rows_F_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, P, Dz, out);
+}
+
+void launch_expand_hessian_rows(hipStream_t st, int n, BarrierParams P, const double* Y, double* out) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(expand_hessian_rows_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, P, Y, out);
 }
 
 void launch_dot(hipStream_t st, int n, const double* x, const double* y, double* scratch, double* out, double* out_host,

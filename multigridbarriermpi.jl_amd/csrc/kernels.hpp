@@ -85,6 +85,10 @@ void launch_barrier_f1(hipStream_t st, int n, BarrierParams P, const double* Dz,
 // Y[q, base_c + slot(a,b)] = w_q d2F/dDz_a dDz_b over cone c's active columns (a<=b),
 // slot = a*nact - a(a-1)/2 + (b-a)
 void launch_barrier_f2(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, double* Y);
+// map_rows of the barrier: out[q] = F(Dz_q) (+inf outside the set);  out[q, :] = vec of the K x K Hessian from the packed
+// slots Y of launch_barrier_f2 (with w = 1)
+void launch_barrier_rows_F(hipStream_t st, int n, BarrierParams P, const double* Dz, double* out);
+void launch_expand_hessian_rows(hipStream_t st, int n, BarrierParams P, const double* Y, double* out);
 // out[0] = sum x_i y_i ; scratch of kReductionHeader + f0_blocks(n) doubles
 // flag_dev / flag_host (nullable pair): *flag_host = *flag_dev, then *flag_dev = 0 (a device flag set by EARLIER launches on the
 // stream travels to pinned host memory with the dot product and is re-armed)

@@ -578,3 +578,37 @@ def test_solve_matches_live_oracle_on_multi_panel_meshes(M, kind, L, p, tol):
     sol = getattr(M, kind + "_mpi_solve")(L=L, p=p)
     z = M.mpi_to_native(sol).z
     assert rel(z, zo) < tol
+
+
+def test_map_rows_recognises_the_barrier_family(M):
+    """`map_rows(F | F1 | F2, x, Dz)` with the row functions of a convex set runs on the device
+    (mgb_map_rows_barrier: the fused kernels of the Newton path with unit weights) and equals the oracle's row maps; any other
+    closure takes the host fallback and gives the same numbers for the same function."""
+    g = M.fem2d_mpi(3)
+    go = O.fem2d(3)
+    Mo = O.amg(go)
+    rng = np.random.default_rng(4)
+    n = Mo.x.shape[0]
+    z0 = O.map_rows(lambda xi: O.DEFAULT_G[2](xi), Mo.x).reshape(-1, order="F")
+    Dz = O.Barrier.apply_D(Mo.D, z0) + 1e-3 * rng.standard_normal((n, 4))
+    hDz = M.HPCMatrix(Dz)
+    for cones, Q in (([([1, 2, 3], 1.5)], O.convex_Euclidian_power([1, 2, 3], 1.5)),
+                     ([([1, 2, 3], 1.0), ("linear", [0], [1.0], 5.0)],
+                      O.ConeIntersection([O.convex_Euclidian_power([1, 2, 3], 1.0), O.LinearBarrier([0], [1.0], 5.0)]))):
+        F, F1, F2 = M.barrier_functions(cones, 4)
+        y0 = M.map_rows(F, g.x, hDz)
+        assert isinstance(y0, M.HPCVector) and rel(y0.to_numpy(), Q.F(Mo.x, Dz)) < KTOL
+        y1 = M.map_rows(F1, g.x, hDz)
+        assert isinstance(y1, M.HPCMatrix) and y1.shape == (n, 4) and rel(y1.to_numpy(), Q.F1(Mo.x, Dz)) < KTOL
+        y2 = M.map_rows(F2, g.x, hDz)
+        assert y2.shape == (n, 16) and rel(y2.to_numpy(), Q.F2(Mo.x, Dz).reshape(n, 16)) < KTOL
+        # w .* y[:, jk] as the Hessian recipe consumes it (test_column_extract.jl:50-80), all on the device
+        col = (g.w * y2.column(1 * 4 + 2)).to_numpy()
+        assert rel(col, Mo.w * Q.F2(Mo.x, Dz)[:, 1, 2]) < KTOL
+        # the same function as an anonymous closure: host fallback, same values
+        yh = M.map_rows(lambda xr, dr: F1(xr, dr), M.HPCMatrix(Mo.x[:5]), M.HPCMatrix(Dz[:5]))
+        assert rel(yh.to_numpy(), Q.F1(Mo.x[:5], Dz[:5])) < KTOL
+    outside = Dz.copy()
+    outside[3, 3] = -1.0                                                    # s < 0: outside the cone -> F = +inf, reported not raised
+    yo = M.map_rows(M.barrier_functions([([1, 2, 3], 1.5)], 4)[0], g.x, M.HPCMatrix(outside)).to_numpy()
+    assert np.isinf(yo[3]) and np.isfinite(np.delete(yo, 3)).all()
