@@ -376,14 +376,16 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
   Dz_.alloc((size_t)n_ * K);
   DzA_.alloc((size_t)n_ * K);
   DzB_.alloc((size_t)n_ * K);
+  DzC_.alloc((size_t)n_ * K);
   v_.alloc((size_t)n_ * K);
   Y_.alloc((size_t)n_ * nY);
   phi_cur_.alloc((size_t)n_ * P.ncones);
   phi_trial_.alloc((size_t)n_ * P.ncones);
   phi_trial2_.alloc((size_t)n_ * P.ncones);
+  phi_trial3_.alloc((size_t)n_ * P.ncones);
   h_flag_.alloc(4);
-  scal_.alloc(8);
-  h_scal_.alloc(8);
+  scal_.alloc(12);      // [0,1] objective parts, [2] |g|^2, [3] <g,n>, [4..9] the speculated trials' (F, c.Dz) pairs
+  h_scal_.alloc(12);
   seq_dev_.alloc(1);
   hip_check(hipMemset(seq_dev_.p, 0, sizeof(unsigned long long)), "memset seq");
   h_seq_.alloc(1);
@@ -414,7 +416,7 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
 }
 
 size_t reduction_scratch_doubles(int n_local, int max_level_unknowns) {
-  return (size_t)2 * std::max(f0_blocks(n_local), f0_blocks(max_level_unknowns)) + 8 + kReductionHeader;      // incl. the ticket words
+  return (size_t)6 * std::max(f0_blocks(n_local), f0_blocks(max_level_unknowns)) + 8 + kReductionHeader;      // three trial points x two sums per block, incl. the ticket words
 }
 
 Amg::Level& Amg::level(int l) {
@@ -432,6 +434,7 @@ Amg::Level& Amg::level(int l) {
   lv.s.alloc(N);
   lv.s_trial.alloc(N);
   lv.s_trial2.alloc(N);
+  lv.s_trial3.alloc(N);
   lv.g_trial.alloc(N);
   lv.g.alloc(N);
   lv.nstep.alloc(N);
@@ -695,15 +698,41 @@ void Amg::enqueue_trial(Level& lv, Trial& T, double step, int slot, HostSignal s
   T.step = step;      // the caller reduces scal_[4..7] over the ranks in ONE collective and copies scal_[3..7] back in one transfer
 }
 
+static const double kSpecSteps[3] = {1.0, kBeta, kBeta * kBeta};
+
+void Amg::enqueue_spec_trials(Level& lv, Trial* spec, HostSignal sig) {
+  const int ns = spec_count();
+  if (ns == 3) {      // one launch, one pass over B (bitwise what three separate launches give)
+    TrialSet T;
+    T.na = 3;
+    for (int q = 0; q < 3; ++q) {
+      T.alpha[q] = -kSpecSteps[q];
+      T.s_out[q] = spec[q].s;
+      T.dz[q] = spec[q].dz;
+      T.phi_out[q] = spec[q].phi;
+      spec[q].step = kSpecSteps[q];
+    }
+    T.out_dev = scal_.p + 4;
+    T.out_host = host_scal(scal_.p + 4);
+    // one pass over B, w, c, Dz0 and the reference distances; per point a Dz and a phi write
+    timer_.begin(ctx_.stream, KC_F0, trial_bytes(lv, true) + 2.0 * n_ * (P_.K + P_.ncones) * 8);
+    launch_trial_set(ctx_.stream, lv.B.view, n_, P_, lv.s.p, lv.nstep.p, T, Dz0_.p, w_.p, c_.p, phi_cur_.p, kFracToBoundary,
+                     partials_.p, sig);
+    timer_.end(ctx_.stream);
+  } else {
+    enqueue_trial(lv, spec[0], kSpecSteps[0], 0);
+    enqueue_trial(lv, spec[1], kSpecSteps[1], 1, sig);
+  }
+}
+
 void Amg::launch_step_graph(Level& lv, Trial* spec) {
-  const void* key[12] = {lv.avals.p, lv.g.p, lv.nstep.p, lv.s.p, spec[0].s, spec[0].phi, spec[0].dz,
-                         spec[1].s,  spec[1].phi, spec[1].dz, phi_cur_.p, Dz0_.p};
+  const void* key[15] = {lv.avals.p, lv.g.p, lv.nstep.p, lv.s.p, spec[0].s, spec[0].phi, spec[0].dz, spec[1].s, spec[1].phi,
+                         spec[1].dz, spec[2].s,  spec[2].phi, spec[2].dz, phi_cur_.p, Dz0_.p};
   for (const auto& g : lv.step_graphs)
-    if (std::equal(key, key + 12, g.key)) {
+    if (std::equal(key, key + 15, g.key)) {
       hip_check(hipGraphLaunch(g.exec, ctx_.stream), "hipGraphLaunch");
-      ++seq_expected_;      // the second trial of the graph signals
-      spec[0].step = 1.0;
-      spec[1].step = kBeta;
+      ++seq_expected_;      // the last trial launch of the graph signals
+      for (int q = 0; q < spec_count(); ++q) spec[q].step = kSpecSteps[q];
       return;
     }
   hipGraph_t graph = nullptr;
@@ -712,11 +741,10 @@ void Amg::launch_step_graph(Level& lv, Trial* spec) {
     lv.gchol.enqueue_chain(ctx_.stream, lv.avals.p, lv.g.p, lv.nstep.p);
     launch_dot(ctx_.stream, lv.plan.N, lv.g.p, lv.nstep.p, partials_.p, scal_.p + 3, host_scal(scal_.p + 3), lv.gchol.fail_flag(),
                h_flag_.p);
-    enqueue_trial(lv, spec[0], 1.0, 0);
     HostSignal sig;      // baked into the graph: the device counter advances on every replay
     sig.seq_dev = seq_dev_.p;
     sig.seq_host = h_seq_.p;
-    enqueue_trial(lv, spec[1], kBeta, 1, sig);
+    enqueue_spec_trials(lv, spec, sig);
   } catch (...) {
     (void)hipStreamEndCapture(ctx_.stream, &graph);
     if (graph) (void)hipGraphDestroy(graph);
@@ -724,7 +752,7 @@ void Amg::launch_step_graph(Level& lv, Trial* spec) {
   }
   hip_check(hipStreamEndCapture(ctx_.stream, &graph), "hipStreamEndCapture");
   Level::StepGraph sg{};
-  std::copy(key, key + 12, sg.key);
+  std::copy(key, key + 15, sg.key);
   hipError_t e = hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
   hip_check(e, "hipGraphInstantiate");
@@ -758,7 +786,7 @@ bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, do
     const bool time_chain = live_ && timer_.enabled() && (st.n_factor % 8) == 5;
     if (flag_rides && spec && !tm && !time_chain && use_graph && lv.flag_armed) {
       launch_step_graph(lv, spec);
-      st.n_f0 += 2;
+      st.n_f0 += spec_count();
     } else {
       if (time_chain) {
         hip_check(hipEventCreate(&e0), "event");
@@ -776,18 +804,17 @@ bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, do
         hip_check(hipMemcpyAsync(h_flag_.p, lv.gchol.fail_flag(), sizeof(int), hipMemcpyDeviceToHost, ctx_.stream), "D2H flag");
       }
       if (spec) {
-        enqueue_trial(lv, spec[0], 1.0, 0);
-        enqueue_trial(lv, spec[1], kBeta, 1, next_signal());
-        ctx_.allreduce_sum(scal_.p + 4, 4);      // sharded: both trials' partial sums in one collective
-        st.n_f0 += 2;
+        enqueue_spec_trials(lv, spec, next_signal());
+        ctx_.allreduce_sum(scal_.p + 4, 2 * spec_count());      // sharded: all speculated trials' partial sums in one collective
+        st.n_f0 += spec_count();
       }
       if (ctx_.world > 1)
-        hip_check(hipMemcpyAsync(h_scal_.p + 3, scal_.p + 3, (spec ? 5 : 1) * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
-                  "D2H inc + trials");
+        hip_check(hipMemcpyAsync(h_scal_.p + 3, scal_.p + 3, (spec ? 1 + 2 * spec_count() : 1) * sizeof(double),
+                                 hipMemcpyDeviceToHost, ctx_.stream), "D2H inc + trials");
     }
     wait_signal("sync solve");
     if (spec)
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < spec_count(); ++q) {
         spec[q].y = h_scal_.p[4 + 2 * q] + t * h_scal_.p[5 + 2 * q];
         spec[q].valid = true;
       }
@@ -874,15 +901,26 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
   st.n_f1++;
   double ymin = y, gmin = gnorm, incmin = INFINITY;
   const double theta = finest ? 0.1 : 0.5;
-  Trial T[2];
+  Trial T[3];
   T[0].s = lv.s_trial.p;
   T[0].phi = phi_trial_.p;
   T[1].s = lv.s_trial2.p;
   T[1].phi = phi_trial2_.p;
+  T[2].s = lv.s_trial3.p;
+  T[2].phi = phi_trial3_.p;
   T[0].dz = DzA_.p;      // every trial keeps its own Dz: the accepted one becomes the iterate's, nothing is re-evaluated
   T[1].dz = DzB_.p;
-  // objective at s - step * nstep in T's buffers (served from the speculative evaluation when it matches)
-  auto eval = [&](Trial& X, double step) {
+  T[2].dz = DzC_.p;
+  // objective at s - step * nstep in slot `pos` (0: the oracle's "current trial", 1: its "next halving"; slot 2 only ever holds
+  // a speculated result).  A speculated evaluation of that very step, wherever it sits, is moved into the slot and served.
+  auto eval = [&](int pos, double step) {
+    if (!(T[pos].valid && T[pos].step == step))
+      for (int q = 0; q < 3; ++q)
+        if (q != pos && T[q].valid && T[q].step == step) {
+          std::swap(T[pos], T[q]);
+          break;
+        }
+    Trial& X = T[pos];
     if (X.valid && X.step == step) return X.y;
     X.y = dev_f0(lv, lv.s.p, t, nullptr, phi_cur_.p, X.phi, X.dz, -step, lv.nstep.p, X.s);
     st.n_f0++;
@@ -895,7 +933,7 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
   while (res.k < maxit && !res.converged) {
     res.k++;
     double inc = 0;
-    T[0].valid = T[1].valid = false;
+    T[0].valid = T[1].valid = T[2].valid = false;
     const double* have = pre;      // Hessian values already assembled for this Dz buffer?
     pre = nullptr;
     if (!dev_f2_solve(lv, Dz_.p, t, st, &inc, speculate ? T : nullptr, have)) {
@@ -912,15 +950,13 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
     }
     // backtracking line search: the trial must be finite (amgb_all_isfinite, src:121), respect the
     // fraction-to-the-boundary rule and satisfy Armijo; then keep halving while the objective improves.
-    // T[0] plays the oracle's "current trial", T[1] its "next halving".
     double step = 1.0, ynext = y, gnext = gnorm;
     bool accepted = false;
     while (step >= kMinStep) {
-      if (!(T[0].valid && T[0].step == step) && T[1].valid && T[1].step == step) std::swap(T[0], T[1]);
-      double yA = eval(T[0], step);
+      double yA = eval(0, step);
       if (std::isfinite(yA) && yA <= y - kArmijo * step * inc) {
         while (step * kBeta >= kMinStep) {
-          const double yB = eval(T[1], step * kBeta);
+          const double yB = eval(1, step * kBeta);
           if (!(std::isfinite(yB) && yB < yA)) break;
           std::swap(T[0], T[1]);
           yA = yB;
@@ -960,10 +996,13 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
   // hand the scratch buffers back (pointer identities may have rotated)
   lv.s_trial.p = T[0].s;
   lv.s_trial2.p = T[1].s;
+  lv.s_trial3.p = T[2].s;
   phi_trial_.p = T[0].phi;
   phi_trial2_.p = T[1].phi;
+  phi_trial3_.p = T[2].phi;
   DzA_.p = T[0].dz;
   DzB_.p = T[1].dz;
+  DzC_.p = T[2].dz;
   return res;
 }
 

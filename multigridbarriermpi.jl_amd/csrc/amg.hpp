@@ -240,7 +240,7 @@ class Amg {
     bool flag_armed = false;      // the pivot flag of gchol is known to be zero (re-armed by the dot kernel of the last solve)
     // captured Newton-step graphs (factorisation chain + <g, n> + both speculative trials), one per set of buffer pointers
     struct StepGraph {
-      const void* key[12];
+      const void* key[15];
       hipGraphExec_t exec;
     };
     std::vector<StepGraph> step_graphs;
@@ -251,7 +251,7 @@ class Amg {
     DevCsrOwned R, B, BT, T;
     MfChol chol;      // symbolic structure (+ host numeric path)
     GpuChol gchol;    // device numeric factorisation / sweeps on the same tree
-    DevBuf<double> s, s_trial, s_trial2, g, g_trial, nstep, avals;
+    DevBuf<double> s, s_trial, s_trial2, s_trial3, g, g_trial, nstep, avals;
     PinnedBuf<double> h_avals, h_g, h_n, h_s;
   };
   struct NewtonResult {
@@ -294,6 +294,11 @@ class Amg {
   bool dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, double* inc, Trial* spec = nullptr,
                     const double* pre_assembled = nullptr);
   void enqueue_trial(Level& lv, Trial& T, double step, int slot, HostSignal sig = HostSignal());
+  // the first kSpecSteps points every line search may visit (steps 1, 1/2, 1/4), speculated behind the solve: on launch-bound
+  // meshes ONE launch of the fused objective kernel evaluates all three (one pass over B); on larger meshes the first two
+  // go out as separate bandwidth-shaped launches (a wasted evaluation costs more than a host round trip there)
+  int spec_count() const { return n_ <= fused_trial_rows_ ? 3 : 2; }
+  void enqueue_spec_trials(Level& lv, Trial* spec, HostSignal sig);
   // single GPU, device solver: factorisation chain, <g, n> (+ pivot flag hand-over) and both speculative trials as ONE
   // hipGraph launch (one per set of buffer pointers; the trial buffers rotate through at most a dozen combinations)
   void launch_step_graph(Level& lv, Trial* spec);
@@ -310,7 +315,8 @@ class Amg {
   Csr dstack_host_;
   DevCsrOwned Dstack_;
   std::vector<std::unique_ptr<Level>> levels_;
-  DevBuf<double> w_, c_, z_, z_save_, Dz0_, Dz0_save_, Dz_, DzA_, DzB_, v_, Y_, partials_, scal_, phi_cur_, phi_trial_, phi_trial2_;
+  DevBuf<double> w_, c_, z_, z_save_, Dz0_, Dz0_save_, Dz_, DzA_, DzB_, DzC_, v_, Y_, partials_, scal_, phi_cur_, phi_trial_, phi_trial2_,
+      phi_trial3_;
   PinnedBuf<int> h_flag_;
   bool host_solve_ = false;
   PinnedBuf<double> h_scal_;

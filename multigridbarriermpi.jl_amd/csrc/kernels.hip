@@ -255,32 +255,36 @@ __global__ __launch_bounds__(kBlock) void barrier_f0_kernel(int n, BarrierParams
 // the barrier terms of those nodes are accumulated straight from LDS.  Saves the waxpby and barrier_f0 launches and
 // the re-read of Dz; bytes = spmv(B) + n (K + 2 + ncones [+ ncones]) 8.
 constexpr int kTrialNodes = 64;
-template <int G>
+// NA = 1..3 trial points x_a = s + alpha_a * nstep share ONE pass over B (each nonzero is read once and feeds NA
+// accumulators; per point the operations and their order are exactly those of the NA = 1 kernel, so every Dz and every sum
+// is bitwise what separate launches give).  The barrier phase runs the points side by side: wave a takes point a.
+template <int G, int NA>
 __global__ __launch_bounds__(kBlock) void trial_f0_kernel(int n, int N, BarrierParams P, const int* __restrict__ rowptr,
                                                            const int* __restrict__ colidx, const double* __restrict__ vals,
-                                                           const double* __restrict__ s, double alpha,
-                                                           const double* __restrict__ nstep, double* s_out,
-                                                           const double* __restrict__ Dz0, double* Dz,
+                                                           const double* __restrict__ s, const double* __restrict__ nstep,
+                                                           TrialSet T, const double* __restrict__ Dz0,
                                                            const double* __restrict__ w, const double* __restrict__ c,
-                                                           const double* __restrict__ phi_ref, double frac,
-                                                           double* __restrict__ phi_out, double* scratch, double* out_dev,
-                                                           double* out_host, HostSignal sig) {
+                                                           const double* __restrict__ phi_ref, double frac, double* scratch,
+                                                           HostSignal sig) {
   __shared__ double lds[kBlock / 64];
-  __shared__ double dzs[kTrialNodes * kMaxK];
+  __shared__ double dzs[NA][kTrialNodes * kMaxK];
   constexpr int GR = kBlock / G;      // rows per pass
   const int K = P.K, lane = threadIdx.x % G, grp = threadIdx.x / G;
-  if (s_out)
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < N; i += (long long)gridDim.x * kBlock)
-      s_out[i] = s[i] + alpha * nstep[i];
-  auto xval = [&](int j) { return nstep ? s[j] + alpha * nstep[j] : s[j]; };
-  double accF = 0.0, accL = 0.0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+    if (T.s_out[a])
+      for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < N; i += (long long)gridDim.x * kBlock)
+        T.s_out[a][i] = s[i] + T.alpha[a] * nstep[i];
+  auto xval = [&](int j, int a) { return nstep ? s[j] + T.alpha[a] * nstep[j] : s[j]; };
+  double accF = 0.0, accL = 0.0;      // of the point this thread's wave evaluates
+  const int pa = threadIdx.x >> 6, pnode = threadIdx.x & 63;
   const int nchunks = (n + kTrialNodes - 1) / kTrialNodes;
   for (int ch = xcd_block(blockIdx.x, gridDim.x); ch < nchunks; ch += gridDim.x) {
     const int q0 = ch * kTrialNodes, nq = min(kTrialNodes, n - q0), nrows = nq * K;
     const long long r0 = (long long)q0 * K;
     for (int rr0 = grp; rr0 < nrows; rr0 += kSpmvU * GR) {
       int b[kSpmvU], e[kSpmvU], ci[kSpmvU];
-      double acc[kSpmvU], base[kSpmvU], va[kSpmvU];
+      double acc[NA][kSpmvU], base[kSpmvU], va[kSpmvU];
 #pragma unroll
       for (int u = 0; u < kSpmvU; ++u) {
         const int rr = rr0 + u * GR;
@@ -297,35 +301,45 @@ __global__ __launch_bounds__(kBlock) void trial_f0_kernel(int n, int N, BarrierP
         va[u] = in ? vals[k] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < kSpmvU; ++u) acc[u] = (ci[u] >= 0) ? va[u] * xval(ci[u]) : 0.0;
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int u = 0; u < kSpmvU; ++u) acc[a][u] = (ci[u] >= 0) ? va[u] * xval(ci[u], a) : 0.0;
 #pragma unroll
       for (int u = 0; u < kSpmvU; ++u)
-        for (int k = b[u] + lane + G; k < e[u]; k += G) acc[u] += vals[k] * xval(colidx[k]);
+        for (int k = b[u] + lane + G; k < e[u]; k += G) {
+          const double vk = vals[k];
+          const int ck = colidx[k];
 #pragma unroll
-      for (int u = 0; u < kSpmvU; ++u) {
-        double a = acc[u];
-#pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) a += __shfl_down(a, o, G);
-        const int rr = rr0 + u * GR;
-        if (lane == 0 && rr < nrows) {
-          const double v = base[u] + a;
-          Dz[r0 + rr] = v;
-          dzs[rr] = v;
+          for (int a = 0; a < NA; ++a) acc[a][u] += vk * xval(ck, a);
         }
-      }
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int u = 0; u < kSpmvU; ++u) {
+          double t = acc[a][u];
+#pragma unroll
+          for (int o = G / 2; o > 0; o >>= 1) t += __shfl_down(t, o, G);
+          const int rr = rr0 + u * GR;
+          if (lane == 0 && rr < nrows) {
+            const double v = base[u] + t;
+            T.dz[a][r0 + rr] = v;
+            dzs[a][rr] = v;
+          }
+        }
     }
     __syncthreads();
-    if ((int)threadIdx.x < nq) {
-      const long long q = q0 + threadIdx.x;
-      const double* dz = dzs + threadIdx.x * K;
+    if (pa < NA && pnode < nq) {      // wave-uniform in pa
+      const long long q = q0 + pnode;
+      const double* dz = dzs[pa] + pnode * K;
       const double* cq = c + q * K;
       const double wq = w[q];
+      double* phi_out = T.phi_out[pa];
       double F = 0.0;
-      for (int ci = 0; ci < P.ncones; ++ci) {
-        Cone k = load_cone(P.cone[ci], dz);
-        if (phi_ref && !(k.phi >= frac * phi_ref[q * P.ncones + ci])) k.ok = false;
-        if (phi_out) phi_out[q * P.ncones + ci] = k.phi;
-        F += k.ok ? (-log(k.phi) - P.cone[ci].mu * log(k.s)) : INFINITY;
+      for (int ci2 = 0; ci2 < P.ncones; ++ci2) {
+        Cone k = load_cone(P.cone[ci2], dz);
+        if (phi_ref && !(k.phi >= frac * phi_ref[q * P.ncones + ci2])) k.ok = false;
+        if (phi_out) phi_out[q * P.ncones + ci2] = k.phi;
+        F += k.ok ? (-log(k.phi) - P.cone[ci2].mu * log(k.s)) : INFINITY;
       }
       accF += wq * F;
       double lin = 0.0;
@@ -334,9 +348,16 @@ __global__ __launch_bounds__(kBlock) void trial_f0_kernel(int n, int N, BarrierP
     }
     __syncthreads();
   }
-  const double r[2] = {block_sum(accF, lds), block_sum(accL, lds)};
-  // the partial goes to the slot of the chunk sequence this block worked on, so the sum is the one of the natural order
-  grid_finish<2>(r, scratch, out_dev, out_host, lds, sig, xcd_block(blockIdx.x, gridDim.x));
+  // per point: only its wave holds non-zero terms, so the block sums are those of the one-point kernel
+  double r[2 * NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    r[2 * a] = block_sum(pa == a ? accF : 0.0, lds);
+    r[2 * a + 1] = block_sum(pa == a ? accL : 0.0, lds);
+  }
+  // the partials go to the slot of the chunk sequence this block worked on, so the sums are those of the natural order;
+  // results land at T.out_dev[0] .. (2 NA consecutive doubles: the points' (F, c.Dz) pairs) and its pinned host twin
+  grid_finish<2 * NA>(r, scratch, T.out_dev, T.out_host, lds, sig, xcd_block(blockIdx.x, gridDim.x));
 }
 
 inline int trial_grid(int n) {
@@ -345,12 +366,18 @@ inline int trial_grid(int n) {
 }
 
 template <int G>
-void trial_launch(hipStream_t st, const DevCsr& B, int n, const BarrierParams& P, const double* s, double alpha,
-                  const double* nstep, double* s_out, const double* Dz0, double* Dz, const double* w, const double* c,
-                  const double* phi_ref, double frac, double* phi_out, double* scratch, double* out_dev, double* out_host,
-                  HostSignal sig) {
-  hipLaunchKernelGGL(trial_f0_kernel<G>, dim3(trial_grid(n)), dim3(kBlock), 0, st, n, B.cols, P, B.rowptr, B.colidx, B.vals, s,
-                     alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, scratch, out_dev, out_host, sig);
+void trial_launch(hipStream_t st, const DevCsr& B, int n, const BarrierParams& P, const double* s, const double* nstep,
+                  const TrialSet& T, const double* Dz0, const double* w, const double* c, const double* phi_ref, double frac,
+                  double* scratch, HostSignal sig) {
+#define MGB_TRIAL_NA(NA)                                                                                                    \
+  hipLaunchKernelGGL((trial_f0_kernel<G, NA>), dim3(trial_grid(n)), dim3(kBlock), 0, st, n, B.cols, P, B.rowptr, B.colidx,   \
+                     B.vals, s, nstep, T, Dz0, w, c, phi_ref, frac, scratch, sig)
+  switch (T.na) {
+    case 1: MGB_TRIAL_NA(1); break;
+    case 2: MGB_TRIAL_NA(2); break;
+    default: MGB_TRIAL_NA(3); break;
+  }
+#undef MGB_TRIAL_NA
 }
 
 // register-only helpers: the D-row indices of a cone are run-time data, so rows are picked / updated with
@@ -559,11 +586,10 @@ void launch_waxpby(hipStream_t st, int n, const double* x, double alpha, const d
 
 int f0_blocks(int n) { return std::max(grid_for(n), trial_grid(n)); }
 
-void launch_trial_f0(hipStream_t st, const DevCsr& B, int n, BarrierParams P, const double* s, double alpha,
-                     const double* nstep, double* s_out, const double* Dz0, double* Dz, const double* w, const double* c,
-                     const double* phi_ref, double frac, double* phi_out, double* scratch, double* out2, double* out2_host,
-                     HostSignal sig) {
-#define MGB_TRIAL(G) trial_launch<G>(st, B, n, P, s, alpha, nstep, s_out, Dz0, Dz, w, c, phi_ref, frac, phi_out, scratch, out2, out2_host, sig)
+void launch_trial_set(hipStream_t st, const DevCsr& B, int n, BarrierParams P, const double* s, const double* nstep,
+                      const TrialSet& T, const double* Dz0, const double* w, const double* c, const double* phi_ref, double frac,
+                      double* scratch, HostSignal sig) {
+#define MGB_TRIAL(G) trial_launch<G>(st, B, n, P, s, nstep, T, Dz0, w, c, phi_ref, frac, scratch, sig)
   switch (B.group) {
     case 1: MGB_TRIAL(1); break;
     case 2: MGB_TRIAL(2); break;
@@ -574,6 +600,21 @@ void launch_trial_f0(hipStream_t st, const DevCsr& B, int n, BarrierParams P, co
     default: MGB_TRIAL(64); break;
   }
 #undef MGB_TRIAL
+}
+
+void launch_trial_f0(hipStream_t st, const DevCsr& B, int n, BarrierParams P, const double* s, double alpha,
+                     const double* nstep, double* s_out, const double* Dz0, double* Dz, const double* w, const double* c,
+                     const double* phi_ref, double frac, double* phi_out, double* scratch, double* out2, double* out2_host,
+                     HostSignal sig) {
+  TrialSet T;
+  T.na = 1;
+  T.alpha[0] = alpha;
+  T.s_out[0] = s_out;
+  T.dz[0] = Dz;
+  T.phi_out[0] = phi_out;
+  T.out_dev = out2;
+  T.out_host = out2_host;
+  launch_trial_set(st, B, n, P, s, nstep, T, Dz0, w, c, phi_ref, frac, scratch, sig);
 }
 
 void launch_barrier_f0(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,

@@ -79,6 +79,22 @@ void launch_trial_f0(hipStream_t st, const DevCsr& B, int n, BarrierParams P, co
                      const double* nstep, double* s_out, const double* Dz0, double* Dz, const double* w, const double* c,
                      const double* phi_ref, double frac, double* phi_out, double* scratch, double* out2,
                      double* out2_host = nullptr, HostSignal sig = HostSignal());
+// Up to three trial points x_a = s + alpha[a] * nstep evaluated by ONE launch of the fused objective kernel (one pass over B):
+// point a leaves x_a in s_out[a] (nullable), D(z + R x_a) in dz[a], its cone distances in phi_out[a] (nullable) and its two
+// sums in out_dev[2 a], out_dev[2 a + 1] (and out_host[...], either pointer nullable).  Bitwise what `na` separate
+// launch_trial_f0 calls give.  scratch: kReductionHeader + 2 * na * f0_blocks(n) doubles.
+struct TrialSet {
+  int na = 0;
+  double alpha[3] = {0.0, 0.0, 0.0};
+  double* s_out[3] = {nullptr, nullptr, nullptr};
+  double* dz[3] = {nullptr, nullptr, nullptr};
+  double* phi_out[3] = {nullptr, nullptr, nullptr};
+  double* out_dev = nullptr;
+  double* out_host = nullptr;
+};
+void launch_trial_set(hipStream_t st, const DevCsr& B, int n, BarrierParams P, const double* s, const double* nstep,
+                      const TrialSet& T, const double* Dz0, const double* w, const double* c, const double* phi_ref, double frac,
+                      double* scratch, HostSignal sig = HostSignal());
 // v[q,k] = w_q (dF/dDz_k + t c[q,k])
 void launch_barrier_f1(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
                        double t, double* v);
