@@ -188,9 +188,10 @@ int mgb_amg_sol_kernels(mgb_amg a, double* ms11, double* bytes11, long long* lau
 /* per-kernel device timings (HIP events on the context stream around `reps` back-to-back launches, rotating over `nrot`
  * distinct copies of every operand so that a working set of nrot x bytes beyond the 256 MiB Infinity Cache is read from
  * HBM), ms and algorithmic bytes per launch:
- * order = apply_D, barrier_f2, hessian_assemble, barrier_f1, restrict, barrier_f0, trial_f0 (the fused trial point +
- * apply_D + barrier_f0 launch every objective evaluation of the solve uses) */
-int mgb_amg_time_kernels(mgb_amg a, int level, int reps, int nrot, double* ms7, double* bytes7);
+ * order = apply_D (as the solve runs it: through the element-local view of B on bandwidth-bound meshes), barrier_f2,
+ * hessian_assemble, barrier_f1, restrict, barrier_f0, trial_f0 (the fused trial point + apply_D + barrier_f0 launch of
+ * launch-bound meshes), apply_D through the plain CSR kernel; bytes8[7] = 1 if slot 0 used the element-local view */
+int mgb_amg_time_kernels(mgb_amg a, int level, int reps, int nrot, double* ms8, double* bytes8);
 
 /* ---- host-only symbolic helpers (no GPU needed; used by the CPU test-suite) ----------------- */
 typedef struct mgb_plan_s* mgb_plan;  /* symbolic products of one level: R, B=D*R, B', Hessian plan T */

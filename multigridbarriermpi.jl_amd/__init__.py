@@ -933,11 +933,14 @@ class AMG:
     def time_kernels(self, l, reps=50, nrot=1):
         """Back-to-back launches of each kernel class; nrot > 1 rotates over that many distinct copies of every operand
         (working set nrot x bytes: beyond 256 MiB the rate is an HBM rate, not an Infinity-Cache rate)."""
-        ms = np.empty(7)
-        by = np.empty(7)
+        ms = np.empty(8)
+        by = np.empty(8)
         call("mgb_amg_time_kernels", self.handle, l, reps, int(nrot), dptr(ms), dptr(by))
         names = ("apply_D", "barrier_f2", "hessian_assemble", "barrier_f1", "restrict", "barrier_f0", "trial_f0")
-        return {k: dict(ms=float(m), bytes=float(b)) for k, m, b in zip(names, ms, by)}
+        out = {k: dict(ms=float(m), bytes=float(b)) for k, m, b in zip(names, ms, by)}
+        out["apply_D"]["element_local"] = bool(by[7])
+        out["apply_D_csr"] = dict(ms=float(ms[7]), bytes=float(by[0]))
+        return out
 
     def __del__(self):
         try:

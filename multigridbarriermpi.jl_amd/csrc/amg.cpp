@@ -101,6 +101,40 @@ void DevCsrOwned::upload(const Csr& A) {
   view.vals = vals.p;
 }
 
+bool DevElCsrOwned::build(const Csr& A, int rows_per_el) {
+  view = DevElCsr();
+  if (rows_per_el < 2 || A.rows == 0 || A.rows % rows_per_el) return false;
+  const int nel = A.rows / rows_per_el;
+  std::vector<std::vector<int>> cols(nel);
+  int cmax = 0;
+  for (int e = 0; e < nel; ++e) {
+    std::vector<int>& c = cols[e];
+    c.assign(A.colidx.begin() + A.rowptr[e * rows_per_el], A.colidx.begin() + A.rowptr[(e + 1) * rows_per_el]);
+    std::sort(c.begin(), c.end());
+    c.erase(std::unique(c.begin(), c.end()), c.end());
+    cmax = std::max(cmax, (int)c.size());
+  }
+  // worth it only when the element's columns are few and reused: <= 255 for the 1-byte index, and on average every staged
+  // entry serves at least two nonzeros
+  if (cmax < 1 || cmax > 255 || (long long)nel * cmax * 2 > (long long)A.nnz()) return false;
+  std::vector<int> ec((size_t)nel * cmax);
+  std::vector<unsigned char> lc(A.nnz());
+  for (int e = 0; e < nel; ++e) {
+    const std::vector<int>& c = cols[e];
+    for (int j = 0; j < cmax; ++j) ec[(size_t)e * cmax + j] = j < (int)c.size() ? c[j] : (c.empty() ? 0 : c[0]);
+    for (int k = A.rowptr[e * rows_per_el]; k < A.rowptr[(e + 1) * rows_per_el]; ++k)
+      lc[k] = (unsigned char)(std::lower_bound(c.begin(), c.end(), A.colidx[k]) - c.begin());
+  }
+  ecols.upload(ec.data(), ec.size());
+  lcol.upload(lc.data(), lc.size());
+  view.rows_per_el = rows_per_el;
+  view.cmax = cmax;
+  view.nel = nel;
+  view.ecols = ecols.p;
+  view.lcol = lcol.p;
+  return true;
+}
+
 // ------------------------------------------------------------------ host symbolic setup
 
 static int state_index(const AmgSpec& spec, const std::string& name) {
@@ -428,6 +462,9 @@ Amg::Level& Amg::level(int l) {
   const double t_up = now_s();
   lv.R.upload(lv.plan.R);
   lv.B.upload(lv.plan.B);
+  // bandwidth-bound meshes evaluate apply_D through the element-local view of B (LDS-staged column tiles, 9 bytes per
+  // nonzero); launch-bound ones (the fused objective kernel's regime) never use it
+  if (n_ > fused_trial_rows_ && geo_.block > 1 && n_ % geo_.block == 0) lv.Bel.build(lv.plan.B, geo_.block * P_.K);
   lv.BT.upload(lv.plan.BT);
   lv.T.upload(lv.plan.T);
   const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
@@ -593,7 +630,8 @@ void Amg::refresh_dz0() { launch_spmv(ctx_.stream, Dstack_.view, z_.p, nullptr, 
 
 void Amg::dev_apply(Level& lv, const double* s_dev, double* dz) {
   timer_.begin(ctx_.stream, KC_APPLY, csr_bytes(lv.B.view, true));
-  launch_spmv(ctx_.stream, lv.B.view, s_dev, Dz0_.p, dz);
+  if (lv.Bel.view.valid()) launch_spmv_el(ctx_.stream, lv.B.view, lv.Bel.view, s_dev, Dz0_.p, dz);
+  else launch_spmv(ctx_.stream, lv.B.view, s_dev, Dz0_.p, dz);
   timer_.end(ctx_.stream);
 }
 
@@ -1192,12 +1230,14 @@ Amg::KernelTimes Amg::time_kernels(int l, int reps, int nrot) {
   // operand sets: set 0 = the level's own buffers, sets 1.. = copies
   struct Set {
     DevCsrOwned B, BT, T;
+    DevElCsrOwned Bel;
     DevBuf<double> s, s2, dz0, dz, dzA, v, Y, g, avals, w, c, phi, phi2, partials, scal;
   };
   std::vector<std::unique_ptr<Set>> sets;
   for (int r = 1; r < nrot; ++r) {
     auto q = std::make_unique<Set>();
     q->B.upload(lv.plan.B);
+    if (lv.Bel.view.valid()) q->Bel.build(lv.plan.B, lv.Bel.view.rows_per_el);
     q->BT.upload(lv.plan.BT);
     q->T.upload(lv.plan.T);
     auto dup = [&](DevBuf<double>& dst, const double* src, size_t cnt) {
@@ -1224,14 +1264,15 @@ Amg::KernelTimes Amg::time_kernels(int l, int reps, int nrot) {
     sets.push_back(std::move(q));
   }
   struct View {
+    DevElCsr Bel;
     DevCsr B, BT, T;
     double *s, *s2, *dz0, *dz, *dzA, *v, *Y, *g, *avals, *w, *c, *phi, *phi2, *partials, *scal;
   };
   std::vector<View> vw;
-  vw.push_back(View{lv.B.view, lv.BT.view, lv.T.view, lv.s.p, lv.s_trial.p, Dz0_.p, Dz_.p, DzA_.p, v_.p, Y_.p, lv.g.p,
+  vw.push_back(View{lv.Bel.view, lv.B.view, lv.BT.view, lv.T.view, lv.s.p, lv.s_trial.p, Dz0_.p, Dz_.p, DzA_.p, v_.p, Y_.p, lv.g.p,
                     lv.avals.p, w_.p, c_.p, phi_cur_.p, phi_trial_.p, partials_.p, scal_.p});
   for (auto& q : sets)
-    vw.push_back(View{q->B.view, q->BT.view, q->T.view, q->s.p, q->s2.p, q->dz0.p, q->dz.p, q->dzA.p, q->v.p, q->Y.p, q->g.p,
+    vw.push_back(View{q->Bel.view, q->B.view, q->BT.view, q->T.view, q->s.p, q->s2.p, q->dz0.p, q->dz.p, q->dzA.p, q->v.p, q->Y.p, q->g.p,
                       q->avals.p, q->w.p, q->c.p, q->phi.p, q->phi2.p, q->partials.p, q->scal.p});
   auto timeit = [&](auto&& fn) {
     for (int r = 0; r < nrot; ++r) fn(vw[r]);  // warm (code objects, first touch)
@@ -1246,8 +1287,14 @@ Amg::KernelTimes Amg::time_kernels(int l, int reps, int nrot) {
   const double n = n_;
   // the Dz every barrier kernel reads must be a feasible point: Dz = Dz0 + B*0
   for (auto& V : vw) launch_spmv(ctx_.stream, V.B, V.s, V.dz0, V.dz);
-  kt.apply_ms = timeit([&](View& V) { launch_spmv(ctx_.stream, V.B, V.s, V.dz0, V.dz); });
+  // apply_D as the solve runs it on this mesh (element-local view where it is built), and through the plain CSR kernel
+  kt.apply_ms = timeit([&](View& V) {
+    if (V.Bel.valid()) launch_spmv_el(ctx_.stream, V.B, V.Bel, V.s, V.dz0, V.dz);
+    else launch_spmv(ctx_.stream, V.B, V.s, V.dz0, V.dz);
+  });
   kt.apply_bytes = csr_bytes(lv.B.view, true);
+  kt.apply_csr_ms = timeit([&](View& V) { launch_spmv(ctx_.stream, V.B, V.s, V.dz0, V.dz); });
+  kt.apply_el = lv.Bel.view.valid() ? 1.0 : 0.0;
   kt.f2_ms = timeit([&](View& V) { launch_barrier_f2(ctx_.stream, n_, P_, V.dz, V.w, V.Y); });
   kt.f2_bytes = n * (K + 1 + nY) * 8;
   kt.assemble_ms = timeit([&](View& V) { launch_spmv(ctx_.stream, V.T, V.Y, nullptr, V.avals); });

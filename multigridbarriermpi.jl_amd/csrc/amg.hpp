@@ -99,6 +99,16 @@ struct DevCsrOwned {
   void upload(const Csr& A);
 };
 
+// Owning element-local view of a device CSR (kernels.hpp: DevElCsr); invalid (nel = 0) when the rows do not come in element
+// blocks with at most 255 distinct columns each
+struct DevElCsrOwned {
+  DevElCsr view;
+  DevBuf<int> ecols;
+  DevBuf<unsigned char> lcol;
+  // rows_per_el consecutive rows of A form an element; returns false (and stays invalid) if A does not fit the format
+  bool build(const Csr& A, int rows_per_el);
+};
+
 struct AmgSpec {
   std::vector<std::pair<std::string, std::string>> state_variables;  // (name, subspace key)
   std::vector<std::pair<std::string, std::string>> D;                // (state var, operator key)
@@ -229,7 +239,7 @@ class Amg {
 
   // raw pieces for benchmarking: run the device part of one F2 evaluation `reps` times
   struct KernelTimes {
-    double apply_ms, f2_ms, assemble_ms, f1_ms, restrict_ms, f0_ms, trial_ms;
+    double apply_ms, f2_ms, assemble_ms, f1_ms, restrict_ms, f0_ms, trial_ms, apply_csr_ms, apply_el;
     double apply_bytes, f2_bytes, assemble_bytes, f1_bytes, restrict_bytes, f0_bytes, trial_bytes;
   };
   KernelTimes time_kernels(int l, int reps, int nrot = 1);      // nrot: rotate over this many distinct copies of every operand
@@ -249,6 +259,7 @@ class Amg {
     }
     LevelPlan plan;
     DevCsrOwned R, B, BT, T;
+    DevElCsrOwned Bel;      // element-local view of B for apply_D on bandwidth-bound meshes
     MfChol chol;      // symbolic structure (+ host numeric path)
     GpuChol gchol;    // device numeric factorisation / sweeps on the same tree
     DevBuf<double> s, s_trial, s_trial2, s_trial3, g, g_trial, nstep, avals;

@@ -858,14 +858,15 @@ int mgb_amg_sol_kernels(mgb_amg a, double* ms11, double* bytes11, long long* lau
     }
   });
 }
-int mgb_amg_time_kernels(mgb_amg a, int level, int reps, int nrot, double* ms7, double* bytes7) {
+int mgb_amg_time_kernels(mgb_amg a, int level, int reps, int nrot, double* ms8, double* bytes8) {
   return guard([&] {
-    need(a && ms7 && bytes7 && reps > 0 && nrot >= 1 && nrot <= 64 && level >= 0 && level < a->amg->L(), "time_kernels: bad arguments");
+    need(a && ms8 && bytes8 && reps > 0 && nrot >= 1 && nrot <= 64 && level >= 0 && level < a->amg->L(), "time_kernels: bad arguments");
     Amg::KernelTimes k = a->amg->time_kernels(level, reps, nrot);
-    const double ms[7] = {k.apply_ms, k.f2_ms, k.assemble_ms, k.f1_ms, k.restrict_ms, k.f0_ms, k.trial_ms};
-    const double by[7] = {k.apply_bytes, k.f2_bytes, k.assemble_bytes, k.f1_bytes, k.restrict_bytes, k.f0_bytes, k.trial_bytes};
-    std::copy(ms, ms + 7, ms7);
-    std::copy(by, by + 7, bytes7);
+    const double ms[8] = {k.apply_ms, k.f2_ms, k.assemble_ms, k.f1_ms, k.restrict_ms, k.f0_ms, k.trial_ms, k.apply_csr_ms};
+    const double by[8] = {k.apply_bytes, k.f2_bytes, k.assemble_bytes, k.f1_bytes, k.restrict_bytes, k.f0_bytes, k.trial_bytes,
+                          k.apply_el};      // last slot: 1 if apply_D (slot 0) ran through the element-local view
+    std::copy(ms, ms + 8, ms8);
+    std::copy(by, by + 8, bytes8);
   });
 }
 

@@ -97,6 +97,67 @@ void spmv_launch(hipStream_t st, const DevCsr& A, const double* x, const double*
   hipLaunchKernelGGL(spmv_kernel<G>, dim3(grid), dim3(kBlock), 0, st, A.rows, A.rowptr, A.colidx, A.vals, x, y0, y);
 }
 
+// Element-local SpMV (DevElCsr): a workgroup takes kElPerBlock consecutive elements per pass, stages their x entries in LDS
+// (thread = (element, column slot): consecutive threads read consecutive ecols entries -- coalesced -- and gather x once per
+// element column), then every lane group forms its row exactly as spmv_kernel<G> does: lane j adds nonzeros j, j + G, ...,
+// fixed shuffle tree -- bitwise the same y.  bytes = nnz * 9 + (rows + 1) * 4 + nel * cmax * 12 + rows * 16.
+template <int G>
+__global__ __launch_bounds__(kBlock) void spmv_el_kernel(int rows, DevElCsr E, const int* __restrict__ rowptr,
+                                                          const double* __restrict__ vals, const double* __restrict__ x,
+                                                          const double* y0, double* y) {
+  extern __shared__ double xs[];      // els_per_pass x cmax
+  const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+  constexpr int GR = kBlock / G;
+  const int rpe = E.rows_per_el;
+  const int els = max(1, min(E.nel, (kBlock * 4) / rpe));      // elements per pass: ~1024 rows
+  const int npass = (E.nel + els - 1) / els;
+  for (int ps = xcd_block(blockIdx.x, gridDim.x); ps < npass; ps += gridDim.x) {
+    const int e0 = ps * els, ne = min(els, E.nel - e0);
+    __syncthreads();      // the previous pass is done with xs
+    for (int idx = threadIdx.x; idx < ne * E.cmax; idx += kBlock) xs[idx] = x[E.ecols[(long long)e0 * E.cmax + idx]];
+    __syncthreads();
+    const long long r0 = (long long)e0 * rpe;
+    const int nrows = (int)min((long long)ne * rpe, (long long)rows - r0);
+    for (int rr0 = grp; rr0 < nrows; rr0 += kSpmvU * GR) {
+      int b[kSpmvU], e[kSpmvU];
+      double acc[kSpmvU], base[kSpmvU];
+#pragma unroll
+      for (int u = 0; u < kSpmvU; ++u) {
+        const int rr = rr0 + u * GR;
+        const bool ok = rr < nrows;
+        b[u] = ok ? rowptr[r0 + rr] : 0;
+        e[u] = ok ? rowptr[r0 + rr + 1] : 0;
+        base[u] = (ok && y0 && lane == 0) ? y0[r0 + rr] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kSpmvU; ++u) {
+        const int rr = rr0 + u * GR;
+        const double* xe = xs + (rr / rpe) * E.cmax;
+        const int k = b[u] + lane;
+        acc[u] = (k < e[u]) ? vals[k] * xe[E.lcol[k]] : 0.0;
+        for (int kk = k + G; kk < e[u]; kk += G) acc[u] += vals[kk] * xe[E.lcol[kk]];
+      }
+#pragma unroll
+      for (int u = 0; u < kSpmvU; ++u) {
+        double a = acc[u];
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) a += __shfl_down(a, o, G);
+        const int rr = rr0 + u * GR;
+        if (lane == 0 && rr < nrows) y[r0 + rr] = base[u] + a;
+      }
+    }
+  }
+}
+
+template <int G>
+void spmv_el_launch(hipStream_t st, const DevCsr& A, const DevElCsr& E, const double* x, const double* y0, double* y) {
+  const int els = std::max(1, std::min(E.nel, (kBlock * 4) / E.rows_per_el));
+  const int npass = (E.nel + els - 1) / els;
+  const int grid = std::max(1, std::min(npass, kMaxBlocks * 4));
+  hipLaunchKernelGGL(spmv_el_kernel<G>, dim3(grid), dim3(kBlock), (size_t)els * E.cmax * sizeof(double), st, A.rows, E, A.rowptr,
+                     A.vals, x, y0, y);
+}
+
 // ---------------------------------------------------------------- reductions
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -576,6 +637,19 @@ void launch_spmv(hipStream_t st, const DevCsr& A, const double* x, const double*
     case 16: spmv_launch<16>(st, A, x, y0, y); break;
     case 32: spmv_launch<32>(st, A, x, y0, y); break;
     default: spmv_launch<64>(st, A, x, y0, y); break;
+  }
+}
+
+void launch_spmv_el(hipStream_t st, const DevCsr& A, const DevElCsr& E, const double* x, const double* y0, double* y) {
+  if (A.rows == 0) return;
+  switch (A.group) {
+    case 1: spmv_el_launch<1>(st, A, E, x, y0, y); break;
+    case 2: spmv_el_launch<2>(st, A, E, x, y0, y); break;
+    case 4: spmv_el_launch<4>(st, A, E, x, y0, y); break;
+    case 8: spmv_el_launch<8>(st, A, E, x, y0, y); break;
+    case 16: spmv_el_launch<16>(st, A, E, x, y0, y); break;
+    case 32: spmv_el_launch<32>(st, A, E, x, y0, y); break;
+    default: spmv_el_launch<64>(st, A, E, x, y0, y); break;
   }
 }
 

@@ -14,6 +14,19 @@ struct DevCsr {
   double* vals = nullptr;
 };
 
+// Element-local view of a CSR matrix whose rows come in element blocks (rows [e * rows_per_el, (e + 1) * rows_per_el)) that
+// only touch a handful of columns each -- B = D R of a broken finite-element space: the 28 rows of a triangle touch its 14
+// continuous dofs.  `ecols[e * cmax + j]` lists element e's columns (padded with its first one) and `lcol[k]` replaces the
+// 4-byte column index of nonzero k by a 1-byte index into that list: the kernel stages the element's x entries in LDS once
+// (one coalesced gather per element instead of one scattered 8-byte gather per nonzero) and reads 9 instead of 12 bytes per
+// nonzero.  rowptr / vals are the CSR's own.
+struct DevElCsr {
+  int rows_per_el = 0, cmax = 0, nel = 0;
+  const int* ecols = nullptr;
+  const unsigned char* lcol = nullptr;
+  bool valid() const { return nel > 0; }
+};
+
 // One term of the barrier, acting on columns of the n x K row-major matrix Dz:
 //   kind 0 -- power cone  Q = {(q,s): s >= |q|^p}  (upstream convex_Euclidian_power), F = -log(s^(2/p) - |q|^2) - mu log s
 //             on columns iq[0..nq) and `is`.  If is2 >= 0 the slack is Dz[is] + Dz[is2] (feasibility phase: the extra column
@@ -52,6 +65,9 @@ struct BarrierParams {
 
 // y = (y0 ? y0 : 0) + A x      (y may alias y0)
 void launch_spmv(hipStream_t st, const DevCsr& A, const double* x, const double* y0, double* y);
+// the same product through the element-local view (bitwise the same y: per row the same lanes add the same terms in the
+// same order; only the x entries come from LDS)
+void launch_spmv_el(hipStream_t st, const DevCsr& A, const DevElCsr& E, const double* x, const double* y0, double* y);
 // out = x + alpha*y
 void launch_waxpby(hipStream_t st, int n, const double* x, double alpha, const double* y, double* out);
 // Reductions finish inside the producing launch (csrc/kernels.hip: grid_finish): `scratch` starts with
