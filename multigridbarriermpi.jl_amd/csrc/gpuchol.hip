@@ -199,43 +199,43 @@ __global__ __launch_bounds__(TB, 3) void front_start_kernel(const GNode* __restr
   __shared__ double sh[2 * PB * LP];
   __shared__ int cb[2][PB];
   STAMP(0);
-  const StartJob job = jobs[blockIdx.x];
-  const GNode nd = nodes[job.node];
-  const int nf = nd.nf, ld = nf + 1, ns = nd.ns;
-  double* F = fronts + nd.off;
+  const StartJob job = jobs[blockIdx.x];      // self-contained: node, children, assembly range
+  const int nf = job.nf, ld = nf + 1, ns = job.ns;
+  double* F = fronts + job.off;
   const int c0 = job.chunk * PB, c1 = min(nf, c0 + PB);
   const int tid = threadIdx.x;
   // child blocks (read-only here, through fronts_ro): entry (boundary row a, boundary column q) of child s at
   // fronts_ro[boff[s] + cld[s] * q + a]; an absent child gets a valid dummy offset that is never selected
-  long long boff[2] = {nd.off, nd.off};
-  int cld[2] = {0, 0};
-  bool has[2] = {false, false};
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-    if (nd.child[s] >= 0) {
-      const GNode c = nodes[nd.child[s]];
-      cld[s] = c.nf + 1;
-      boff[s] = c.off + (long long)cld[s] * c.ns + c.ns;
-      has[s] = true;
-    }
-  const int* __restrict__ inv0 = pinv + (has[0] ? nd.iofs : 0);
-  const int* __restrict__ inv1 = pinv + (has[1] ? nd.iofs + ld : 0);
+  const long long boff[2] = {job.boff[0], job.boff[1]};
+  const int cld[2] = {job.cld[0], job.cld[1]};
+  const bool has[2] = {job.cld[0] > 0, job.cld[1] > 0};
+  const int* __restrict__ inv0 = pinv + (has[0] ? job.iofs : 0);
+  const int* __restrict__ inv1 = pinv + (has[1] ? job.iofs + ld : 0);
+  const int i = c0 + job.rb * TB + tid;        // one row per thread: the workgroup owns rows [c0 + 256 rb, +256)
+  // everything that only needs the descriptor is requested together: the column maps, this thread's row maps, the first
+  // assembly indices and the right-hand-side permutation (the chain is descriptor -> indices -> data)
   if (tid < 2 * PB) {
     const int s = tid / PB, c = c0 + tid % PB;
     cb[s][tid % PB] = (has[s] && c < c1) ? (s ? inv1 : inv0)[c] : -1;
   }
+  const int ra0 = (i <= nf && has[0]) ? inv0[i] : -1, ra1 = (i <= nf && has[1]) ? inv1[i] : -1;
+  const int ka = job.a0 + tid;
+  const int apos0 = (ka < job.a1) ? asm_pos[ka] : -1, asrc0 = (ka < job.a1) ? asm_src[ka] : 0;
+  const bool rhs_wg = (c0 + job.rb * TB <= nf && nf < c0 + (job.rb + 1) * TB);      // this workgroup owns the right-hand-side row
+  const int crhs = c0 + tid;
+  const int prm = (rhs_wg && crhs < min(c1, ns)) ? perm[job.first + crhs] : -1;
+  const double aval0 = vals[asrc0];
+  const double bval = (prm >= 0) ? b[prm] : 0.0;
   __syncthreads();
   STAMP(1);
   const double* __restrict__ B0 = fronts_ro + boff[0];
   const double* __restrict__ B1 = fronts_ro + boff[1];
-  const int i = c0 + job.rb * TB + tid;        // one row per thread: the workgroup owns rows [c0 + 256 rb, +256)
   if (i <= nf && !has[0] && !has[1]) {      // leaf front (workgroup-uniform): nothing to gather, just clear
     const int cend = min(c1, i + 1);
 #pragma unroll
     for (int q = 0; q < PB; ++q)
       if (c0 + q < cend) F[(long long)ld * (c0 + q) + i] = 0.0;
   } else if (i <= nf) {
-    const int ra0 = has[0] ? inv0[i] : -1, ra1 = has[1] ? inv1[i] : -1;
     const int cend = min(c1, i + 1);       // lower triangle: columns c <= i (row nf: every column)
     double v[PB];
     // branch-free: every load is issued (clamped to a valid address) before any is consumed
@@ -253,9 +253,9 @@ __global__ __launch_bounds__(TB, 3) void front_start_kernel(const GNode* __restr
   }
   __syncthreads();
   STAMP(2);
-  for (int k = job.a0 + tid; k < job.a1; k += TB) F[asm_pos[k]] += vals[asm_src[k]];
-  if (c0 + job.rb * TB <= nf && nf < c0 + (job.rb + 1) * TB)      // this workgroup owns the right-hand-side row
-    for (int c = c0 + tid; c < min(c1, ns); c += TB) F[(long long)ld * c + nf] += b[perm[nd.first + c]];
+  if (apos0 >= 0) F[apos0] += aval0;      // first batch from registers, the rest (large fronts) the long way
+  for (int k = job.a0 + TB + tid; k < job.a1; k += TB) F[asm_pos[k]] += vals[asm_src[k]];
+  if (prm >= 0) F[(long long)ld * crhs + nf] += bval;      // min(c1, ns) - c0 <= 32 <= TB columns: one per thread
   if (job.chunk == 0 && job.rb == 0 && ns > 0) {
     __syncthreads();
     STAMP(3);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(TB, 3) void front_start_kernel(const GNode* __restr
     }
     __syncthreads();
     STAMP(5);
-    factor_diag_block(D, kw, sh + PB * LP, linv + nd.loff, fail, prof);
+    factor_diag_block(D, kw, sh + PB * LP, linv + job.loff, fail, prof);
   }
   STAMP(7);
 }
@@ -584,6 +584,18 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int* __restrict__ inv1 = pinv + (has[1] ? t.iofs + ld : 0);
   const double* __restrict__ B0 = fronts_ro + t.boff[0];
   const double* __restrict__ B1 = fronts_ro + t.boff[1];
+  // The loads of this kernel form dependent chains (descriptor -> index lists -> data); everything that only needs the
+  // descriptor is requested NOW -- the first batch of assembly indices and the right-hand-side permutation next to the index
+  // maps, their values next to the children's entries -- so the chain is three round trips deep instead of seven.
+  int apos[4], asrc[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int k = t.a0 + u * TB + tid;
+    apos[u] = (k < t.a1) ? asm_pos[k] : -1;
+    asrc[u] = (k < t.a1) ? asm_src[k] : 0;
+  }
+  const bool rhs_tile = (nf >= r0 && nf < r0 + TS);      // this tile holds the right-hand-side row
+  const int prm = (rhs_tile && tid < ns) ? perm[t.first + tid] : -1;
   // index maps of the tile's rows, columns and of the pivot columns (parent front index -> child boundary index)
   for (int idx = tid; idx < 2 * (2 * TS + PB); idx += TB) {
     const int s = idx / (2 * TS + PB), q = idx % (2 * TS + PB);
@@ -592,6 +604,10 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     else if (q < 2 * TS) rowJ[s][q - TS] = (has[s] && c0 + q - TS <= nf) ? iv[c0 + q - TS] : -1;
     else piv[s][q - 2 * TS] = (has[s] && q - 2 * TS < ns) ? iv[q - 2 * TS] : -1;
   }
+  double aval[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) aval[u] = vals[asrc[u]];
+  const double bval = (prm >= 0) ? b[prm] : 0.0;
   __syncthreads();
   // gather (every load issued before it is consumed, clamped to a valid address when the entry has no contribution)
   auto child = [&](int a0, int q0, int a1, int q1) {
@@ -635,8 +651,20 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
   __syncthreads();
   STAMP(1);
-  // assembled entries (all in pivot columns) and right-hand side of the pieces this tile holds
-  for (int k0a = t.a0; k0a < t.a1; k0a += 4 * TB) {      // 4 entries per thread and pass: loads batched
+  // assembled entries (all in pivot columns) and right-hand side of the pieces this tile holds; the first batch is in
+  // registers already
+  auto add_entry = [&](int pos, double v) {
+    if (pos < 0) return;
+    const int col = pos / ld, row = pos - col * ld;
+    if (row < ns) D[row * LP + col] += v;
+    else {
+      if (row >= r0 && row < r0 + TS) ATI[col * TP + row - r0] += v;
+      if (!diag && row >= c0 && row < c0 + TS) ATJ[col * TP + row - c0] += v;
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < 4; ++u) add_entry(apos[u], aval[u]);
+  for (int k0a = t.a0 + 4 * TB; k0a < t.a1; k0a += 4 * TB) {      // further batches (large fronts only)
     int pos[4], src[4];
     double v[4];
 #pragma unroll
@@ -648,18 +676,9 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = vals[src[u]];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (pos[u] < 0) continue;
-      const int col = pos[u] / ld, row = pos[u] - col * ld;
-      if (row < ns) D[row * LP + col] += v[u];
-      else {
-        if (row >= r0 && row < r0 + TS) ATI[col * TP + row - r0] += v[u];
-        if (!diag && row >= c0 && row < c0 + TS) ATJ[col * TP + row - c0] += v[u];
-      }
-    }
+    for (int u = 0; u < 4; ++u) add_entry(pos[u], v[u]);
   }
-  if (nf >= r0 && nf < r0 + TS)
-    for (int q = tid; q < ns; q += TB) ATI[q * TP + nf - r0] += b[perm[t.first + q]];
+  if (prm >= 0) ATI[tid * TP + nf - r0] += bval;      // ns <= 32 <= TB: one entry per thread
   __syncthreads();
   factor_diag_block<NARROW>(D, kw, Lo, (t.ti == 0 && t.tj == 0) ? linv + t.loff : nullptr, fail, nullptr);
   for (int idx = tid; idx < PB * PB; idx += TB) Lc[lq_index(idx % PB, idx / PB)] = Lo[(idx % PB) * LP + idx / PB];     // L[m][j], quad order
@@ -1051,6 +1070,21 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
         j.node = t;
         j.chunk = ch;
         j.rb = rb;
+        j.off = nodes[t].off;
+        j.loff = nodes[t].loff;
+        j.nf = nodes[t].nf;
+        j.ns = nodes[t].ns;
+        j.iofs = nodes[t].iofs;
+        j.first = nodes[t].first;
+        for (int sI = 0; sI < 2; ++sI) {
+          j.boff[sI] = nodes[t].off;
+          j.cld[sI] = 0;
+          if (nodes[t].child[sI] >= 0) {
+            const GNode& c = nodes[nodes[t].child[sI]];
+            j.cld[sI] = c.nf + 1;
+            j.boff[sI] = c.off + (long long)j.cld[sI] * c.ns + c.ns;
+          }
+        }
         j.a0 = (int)asrc.size();
         while (q < m && key(ord[q]) == (long long)ch * 65536 + rb) {
           const int pos = sym.a_pos_[t][ord[q]], col = pos / nf, row = pos % nf;

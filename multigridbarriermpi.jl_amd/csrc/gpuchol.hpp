@@ -50,7 +50,12 @@ struct GNode {
   int a0, a1;         // range of this node's entries in the assembly list
 };
 
-struct StartJob {     // one workgroup of front_start: 32 columns x 256 rows (counted from the chunk's first row) of one front
+struct StartJob {     // one workgroup of front_start: 32 columns x 256 rows (counted from the chunk's first row) of one front,
+                      // with everything of the node and its children inline (no dependent descriptor loads)
+  long long off, loff;      // front, first pivot block
+  long long boff[2];        // first boundary entry of each child's front (own front offset if absent)
+  int cld[2];               // child leading dimensions (0 = no child)
+  int nf, ns, iofs, first;
   int node, chunk, rb;
   int a0, a1;         // range of the (column-sorted) assembly list
 };
