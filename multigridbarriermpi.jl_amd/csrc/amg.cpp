@@ -713,8 +713,10 @@ double Amg::dev_f1(Level& lv, const double* dz, double t, double* g_out, SolveSt
               "D2H g");
   if (pre && st && !host_solve_) {
     ensure_chol(lv);
-    if (!ev_f1_) hip_check(hipEventCreateWithFlags(&ev_f1_, hipEventDisableTiming), "event");
-    hip_check(hipEventRecord(ev_f1_, ctx_.stream), "record f1");
+    if (ctx_.world > 1) {      // single GPU: the dot kernel's completion signal is what the host waits for -- no event packet
+      if (!ev_f1_) hip_check(hipEventCreateWithFlags(&ev_f1_, hipEventDisableTiming), "event");      // (the packet cost ~10 us per step)
+      hip_check(hipEventRecord(ev_f1_, ctx_.stream), "record f1");
+    }
     enqueue_f2_assemble(lv, dz, *st);
     *pre = dz;
     if (ctx_.world == 1) wait_signal("sync f1");      // |g| is on the host; the Hessian assembly keeps running behind it
