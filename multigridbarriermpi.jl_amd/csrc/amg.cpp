@@ -1110,11 +1110,15 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   st.ts.push_back(t);
   st.c_dot_Dz.push_back(c_dot_dz());
   int k = 1;
-  while (t <= 1 / opt.tol && kappa > 1 && k < opt.maxit) {
+  // the continuation ends at a FIXED t: the first value of the nominal sequence t0 kappa0^k beyond 1 / tol (oracle amgb_core:
+  // otherwise the last t, and with it z to ~1e-6, depends on the rounding-sensitive history of kappa reductions)
+  double t_stop = t;
+  while (t_stop <= 1 / opt.tol) t_stop *= kappa0;
+  while (t < t_stop && kappa > 1 && k < opt.maxit) {
     k++;
     std::fill(its.begin(), its.end(), 0);
     while (kappa > 1) {
-      const double t1 = kappa * t;
+      const double t1 = std::min(kappa * t, t_stop);
       hip_check(hipMemcpyAsync(z_save_.p, z_.p, zbytes, hipMemcpyDeviceToDevice, ctx_.stream), "save z");
       hip_check(hipMemcpyAsync(Dz0_save_.p, Dz0_.p, dzbytes, hipMemcpyDeviceToDevice, ctx_.stream), "save Dz0");
       std::vector<long long> it1(L, 0);
@@ -1144,7 +1148,7 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   }
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   st.t_elapsed = now_s() - t_begin;
-  if (t <= 1 / opt.tol) throw NumericError("amgb: convergence failure (kappa collapsed)");
+  if (t < t_stop) throw NumericError("amgb: convergence failure (kappa collapsed)");
 }
 
 // ------------------------------------------------------------------ fine-grained entry points

@@ -781,11 +781,17 @@ def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max
     its.append(it0); ts.append(t); cdots.append(cdot(Dz0))
     k = 1
     stopped = early_stop is not None and early_stop(Dz0)
-    while t <= 1 / tol and kappa > 1 and k < maxit and not stopped:
+    # The continuation ends at a FIXED barrier parameter: t_stop = the first value of the nominal sequence t0 * kappa0^k beyond
+    # 1 / tol (1e8 for the defaults).  Without it the last t depends on the history of kappa reductions -- a discrete, rounding
+    # sensitive path -- and two correct runs end at different central points (fem2d L=7, p=1: t = 1.0e8 or 1.8e8, z 1e-6 apart).
+    t_stop = t
+    while t_stop <= 1 / tol:
+        t_stop *= kappa0
+    while t < t_stop and kappa > 1 and k < maxit and not stopped:
         k += 1
         it_k = np.zeros(len(M.R), dtype=np.int64)
         while kappa > 1:
-            t1 = kappa * t
+            t1 = min(kappa * t, t_stop)
             SOL = amgb_step(B, M, z, Dz0, t1 * c, max_newton, lam_tol, log, schedule)
             it_k += SOL["its"]
             if SOL["converged"]:
@@ -798,7 +804,7 @@ def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max
                 kappa = 1.0
         its.append(it_k); ts.append(t); cdots.append(cdot(Dz0))
         stopped = early_stop is not None and early_stop(Dz0)
-    if t <= 1 / tol and not stopped:
+    if t < t_stop and not stopped:
         raise RuntimeError("amgb: convergence failure at t=%g kappa=%g" % (t, kappa))
     return dict(z=z, its=np.array(its).T, ts=np.array(ts), c_dot_Dz=np.array(cdots),
                 t_elapsed=time.time() - t_begin)
