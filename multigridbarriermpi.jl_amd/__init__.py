@@ -105,9 +105,14 @@ def torch_allreduce(dist, device: int, group=None):
                                              "version": 2, "strides": None}
 
     on_device = dist.get_backend(group) == "nccl"
+    views = {}      # (ptr, count) -> tensor view of the library's buffer: the same few buffers come back every Newton step
 
     def allreduce(ptr, count):
-        t = torch.as_tensor(_Raw(ptr, count), device=torch.device("cuda", device))
+        t = views.get((ptr, count))
+        if t is None:
+            if len(views) > 256:
+                views.clear()
+            t = views[(ptr, count)] = torch.as_tensor(_Raw(ptr, count), device=torch.device("cuda", device))
         if on_device:
             dist.all_reduce(t, group=group)
         else:

@@ -111,8 +111,8 @@ def test_parabolic_2d_L6_matches_oracle_golden(M):
     for k in gold["keep"]:
         uk, rk = sol.u[int(k)], gold["u_%d" % int(k)]
         print("parabolic L=6 snapshot %d: u rel l2 %.3e, all columns %.3e" % (k, rel(uk[:, 0], rk[:, 0]), rel(uk, rk)))
-        assert rel(uk[:, 0], rk[:, 0]) < 1e-10          # u at the reference's bar (test/test_parabolic.jl:93-104)
-        assert rel(uk, rk) < 1e-8                       # slack columns: flat directions, O(cond * eps)
+        assert rel(uk[:, 0], rk[:, 0]) < 1e-10          # u at the reference's bar (test/test_parabolic.jl:93-104); measured <= 1e-12
+        assert rel(uk, rk) < 1e-9                       # slack columns: flat directions, O(cond * eps); measured <= 2.5e-11
 
 
 @pytest.mark.parametrize("kind,L,p", [("fem1d", 3, 1.0), ("fem2d", 3, 1.0), ("fem2d", 2, 2.0)])

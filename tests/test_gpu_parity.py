@@ -443,7 +443,8 @@ def test_headline_sizes_match_oracle_goldens(M, kind, L, p):
     """BASELINE.json configs at full size -- fem2d L=7 (the bench workload, p = 1 and 1.5) and fem3d L=4 -- against
     z of the CPU oracle on the same mesh (tests/golden/make_golden_large.py; minutes of host time per case, so the
     GPU box reads the committed vectors).  Bar: relative l2 <= 1e-10 (BASELINE.json north_star); the reference's
-    own two implementations differ by 3.3e-13 in the sup norm at L=7 (docs/src/guide.md:252)."""
+    own two implementations differ by 3.3e-13 in the sup norm at L=7 (docs/src/guide.md:252).  Measured: 7.0e-13 (p = 1, 466
+    Newton steps here against 527 in the oracle: different kappa histories, same end point), 2.5e-13 (p = 1.5)."""
     gold = np.load(os.path.join(HERE, "golden", "large_%s_L%d_p%s.npz" % (kind, L, str(p).replace(".", "_"))))
     sol = getattr(M, kind + "_mpi_solve")(L=L, p=p)
     z = M.mpi_to_native(sol).z
@@ -568,12 +569,12 @@ def test_fused_and_separate_objective_kernels_agree(M, monkeypatch):
     assert np.array_equal(A.apply_D(2, s), B.apply_D(2, s))
 
 
-@pytest.mark.parametrize("kind,L,p,tol", [("fem2d", 5, 1.5, ZTOL), ("fem2d", 6, 2.0, ZTOL), ("fem2d", 5, 1.0, 5e-10)])
+@pytest.mark.parametrize("kind,L,p,tol", [("fem2d", 5, 1.5, ZTOL), ("fem2d", 6, 2.0, ZTOL), ("fem2d", 5, 1.0, ZTOL)])
 def test_solve_matches_live_oracle_on_multi_panel_meshes(M, kind, L, p, tol):
     """Meshes whose elimination trees have multi-panel fronts (front_step, the matrix-core updates, the backward
-    split) against a live oracle run (2-20 s of host time).  Measured: 1e-14 (L=5, p=1.5), 1.3e-13 (L=6, p=2),
-    6e-11 (L=5, p=1: total variation is ill-conditioned enough that two correct runs with different rounding
-    orders differ at that level, hence the looser bound on that case only)."""
+    split) against a live oracle run (2-20 s of host time).  Measured: 1e-14 (L=5, p=1.5), 1.3e-13 (L=6, p=2); the p = 1
+    case (total variation, the ill-conditioned one) is back at the common 1e-10 bound since the continuation ends at a fixed
+    t (round 1 needed 5e-10 there: the two runs could end at different t)."""
     zo = getattr(O, kind + "_solve")(L=L, p=p).z
     sol = getattr(M, kind + "_mpi_solve")(L=L, p=p)
     z = M.mpi_to_native(sol).z
