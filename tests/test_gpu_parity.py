@@ -613,3 +613,21 @@ def test_map_rows_recognises_the_barrier_family(M):
     outside[3, 3] = -1.0                                                    # s < 0: outside the cone -> F = +inf, reported not raised
     yo = M.map_rows(M.barrier_functions([([1, 2, 3], 1.5)], 4)[0], g.x, M.HPCMatrix(outside)).to_numpy()
     assert np.isinf(yo[3]) and np.isfinite(np.delete(yo, 3)).all()
+
+
+def test_end_point_does_not_depend_on_summation_order(M):
+    """The continuation ends at a fixed t, so z must not depend on mathematically neutral choices that
+    change rounding and with it the kappa history: another split of the backward sweep, another elimination tree, separate
+    instead of fused objective kernels.  fem2d L=6, p=1 (total variation: the ill-conditioned case), fresh process per variant
+    (the knobs are read once); before the fixed end point such variants could land 1e-6 apart (profiles/r2_robust_sweep.txt)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "robust_sweep.py"), "6", "1.0"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-500:]
+    rows = [ln for ln in r.stdout.splitlines() if "|z - z_default|" in ln]
+    assert len(rows) == 5, r.stdout
+    for ln in rows:
+        assert "t_final 1e+08" in ln, ln
+        assert float(ln.rsplit("=", 1)[1]) < ZTOL, ln
