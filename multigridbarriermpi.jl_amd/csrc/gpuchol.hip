@@ -279,35 +279,14 @@ __global__ __launch_bounds__(TB, 3) void front_start_kernel(const GNode* __restr
 // The tj == 0 tiles store L_I into the upper triangle (L[i][k] at row k, column i).  The first `npiv`
 // workgroups of the launch are pivot workgroups (pivot_path): one per front that has a next panel, they do only
 // what the NEXT launch waits for -- the 32 panel rows, the 32x32 corner of the update and its factorisation.
-// One row x of X L11' = A (A, X: 1 x 32 in registers f) by right-looking substitution against the pivot block
-// Lc (LDS, column-major: Lc[32 j + m] = L[m][j], reciprocal diagonal).  Software pipeline: column j+1 of L11
-// is requested (all its LDS reads in flight) before column j is consumed; the empty asm keeps the compiler
-// from sinking the reads back next to their uses.
-template <bool EXIT = false>
-__device__ inline void trsm_row(double (&f)[PB], const double* Lc, int kw = PB) {
-  double lc[2][PB];
-#pragma unroll
-  for (int m = 0; m < PB; ++m) lc[0][m] = Lc[m];
-#pragma unroll
-  for (int j = 0; j < PB; ++j) {
-    if (EXIT && (j & 7) == 0 && j >= kw) break;      // identity padding
-    if (j + 1 < PB) {
-#pragma unroll
-      for (int m = (j + 1) & ~1; m < PB; ++m) lc[(j + 1) & 1][m] = Lc[(j + 1) * PB + m];
-    }
-    asm volatile("" ::: "memory");
-    const double fj = f[j] * lc[j & 1][j];          // diagonal slot holds 1 / L[j][j]
-    f[j] = fj;
-#pragma unroll
-    for (int m = j + 1; m < PB; ++m) f[m] = fma(-fj, lc[j & 1][m], f[m]);
-  }
-}
-
-// The same substitution with FOUR lanes per row (a quad: lanes 4 r .. 4 r + 3 of a wave, lane c4 owning the entries
+// Every row x of X L11' = A (A, X: 1 x 32) is solved by right-looking substitution against the pivot block (LDS, reciprocal
+// diagonal), software pipelined: the columns of L11 are requested two steps ahead of their use.
+// The substitution runs with FOUR lanes per row (a quad: lanes 4 r .. 4 r + 3 of a wave, lane c4 owning the entries
 // m = c4, c4 + 4, .. of the row in f[0..8)): the 496 multiply-adds of a row are split four ways and the solved entry
 // x_j travels from its owner to the other three lanes with a quad-broadcast DPP move (one VALU pass, no LDS), so a wave
 // solves 16 rows and all four waves of a workgroup work -- with one lane per row a wave spent ~3 us on its 64 rows while
-// two or three waves idled.  Operation order per entry is that of trsm_row: bitwise the same result.
+// two or three waves idled.  Operation order per entry is that of the one-lane-per-row loop (for j: x_j = f_j / L_jj;
+// f_m -= x_j L_mj, m > j): bitwise the same result.
 // Lq: the pivot block in "quad" order, Lq[32 j + 8 (m & 3) + (m >> 2)] = L[m][j] (reciprocal diagonal), so that the
 // entries of column j a lane needs are contiguous (b128 LDS reads).
 __device__ __forceinline__ int lq_index(int m, int j) { return 32 * j + 8 * (m & 3) + (m >> 2); }
@@ -320,82 +299,63 @@ __device__ __forceinline__ double quad_bcast(double v) {
   return __hiloint2double(hi, lo);
 }
 
-template <int J>
+// PACKED: the factor is read straight from the row-major packed lower triangle (front_leaf keeps no second copy: LDS is what
+// limits its four workgroups per CU); entries above the diagonal are never used (their slot reads a valid, ignored word)
+template <int J, bool PACKED>
 __device__ __forceinline__ void trsm_quad_load(double (&col)[PB / 4], double& diag, const double* Lq, int c4) {
   if constexpr (J < PB) {
+    if (PACKED) {
 #pragma unroll
-    for (int k = J >> 2; k < PB / 4; ++k) col[k] = Lq[32 * J + 8 * c4 + k];      // this lane's entries of column J: L[c4 + 4 k][J]
-    diag = Lq[32 * J + 8 * (J & 3) + (J >> 2)];                                   // 1 / L[J][J]
+      for (int k = J >> 2; k < PB / 4; ++k) col[k] = Lq[lo_packed(c4 + 4 * k, J)];
+      diag = Lq[lo_packed(J, J)];
+    } else {
+#pragma unroll
+      for (int k = J >> 2; k < PB / 4; ++k) col[k] = Lq[32 * J + 8 * c4 + k];      // this lane's entries of column J: L[c4 + 4 k][J]
+      diag = Lq[32 * J + 8 * (J & 3) + (J >> 2)];                                   // 1 / L[J][J]
+    }
   }
 }
 
 // software pipeline: the entries of column J + 2 are requested before column J is consumed (two columns in flight cover
 // the LDS latency of the short steps); the empty asm keeps the compiler from hoisting ALL columns (it did: 372 VGPRs)
 // or sinking the loads next to their uses
-template <int J, bool EXIT>
+template <int J, bool EXIT, bool PACKED>
 __device__ __forceinline__ void trsm_quad_step(double (&f)[PB / 4], const double* Lq, int c4, int kw, const double (&col)[PB / 4],
                                                double diag, const double (&col1)[PB / 4], double diag1) {
   if constexpr (J < PB) {
     constexpr int owner = J & 3, kk = J >> 2;
     if (EXIT && (J & 7) == 0 && J >= kw) return;      // identity padding (workgroup-uniform)
     double col2[PB / 4], diag2 = 0.0;
-    trsm_quad_load<J + 2>(col2, diag2, Lq, c4);
+    trsm_quad_load<J + 2, PACKED>(col2, diag2, Lq, c4);
     asm volatile("" ::: "memory");
     const double fj = quad_bcast<owner>(f[kk] * diag);
     const double lkk = (c4 > owner) ? col[kk] : 0.0;     // entries of this lane left of / on the diagonal: no update
     f[kk] = (c4 == owner) ? fj : fma(-fj, lkk, f[kk]);
 #pragma unroll
     for (int k = kk + 1; k < PB / 4; ++k) f[k] = fma(-fj, col[k], f[k]);
-    trsm_quad_step<J + 1, EXIT>(f, Lq, c4, kw, col1, diag1, col2, diag2);
+    trsm_quad_step<J + 1, EXIT, PACKED>(f, Lq, c4, kw, col1, diag1, col2, diag2);
   }
 }
 
-template <bool EXIT = false>
+template <bool EXIT = false, bool PACKED = false>
 __device__ __forceinline__ void trsm_quad(double (&f)[PB / 4], const double* Lq, int c4, int kw = PB) {
   double col[PB / 4], diag = 0.0, col1[PB / 4], diag1 = 0.0;
-  trsm_quad_load<0>(col, diag, Lq, c4);
-  trsm_quad_load<1>(col1, diag1, Lq, c4);
-  trsm_quad_step<0, EXIT>(f, Lq, c4, kw, col, diag, col1, diag1);
+  trsm_quad_load<0, PACKED>(col, diag, Lq, c4);
+  trsm_quad_load<1, PACKED>(col1, diag1, Lq, c4);
+  trsm_quad_step<0, EXIT, PACKED>(f, Lq, c4, kw, col, diag, col1, diag1);
 }
 
 // X L11' = A for the 64 rows of a staged panel block AT (AT[q * TP + r] = (row r, panel column q)), in place, by all four
 // waves: wave w takes rows 16 w .. 16 w + 15, four lanes per row.
-template <bool EXIT = false>
+template <bool EXIT = false, bool PACKED = false>
 __device__ __forceinline__ void trsm_block64(double* AT, int TP, const double* Lq, int kw = PB) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = 16 * w + (lane >> 2), c4 = lane & 3;
   double f[PB / 4];
 #pragma unroll
   for (int k = 0; k < PB / 4; ++k) f[k] = AT[(c4 + 4 * k) * TP + r];
-  trsm_quad<EXIT>(f, Lq, c4, kw);
+  trsm_quad<EXIT, PACKED>(f, Lq, c4, kw);
 #pragma unroll
   for (int k = 0; k < PB / 4; ++k) AT[(c4 + 4 * k) * TP + r] = f[k];
-}
-
-// the same substitution straight from the row-major PACKED factor Lo (broadcast reads do not care about the
-// stride) with a one-column register window: front_leaf_kernel trades the last LDS latency for occupancy
-__device__ inline void trsm_row_lo(double (&f)[PB], const double* Lo, int kw) {
-#pragma unroll
-  for (int j = 0; j < PB; ++j) {
-    if ((j & 7) == 0 && j >= kw) break;      // identity padding
-    // the column in two register windows of 16 (the kernel runs at 128 VGPRs, f alone takes 64)
-    constexpr int H = PB / 2;
-    const int m0 = j, m1 = (j < H) ? H : PB;
-    double lc[H];
-#pragma unroll
-    for (int m = m0; m < m1; ++m) lc[m - m0] = Lo[lo_packed(m, j)];
-    asm volatile("" ::: "memory");
-    const double fj = f[j] * lc[0];
-    f[j] = fj;
-#pragma unroll
-    for (int m = m0 + 1; m < m1; ++m) f[m] = fma(-fj, lc[m - m0], f[m]);
-    if (j < H) {
-#pragma unroll
-      for (int m = H; m < PB; ++m) lc[m - H] = Lo[lo_packed(m, j)];
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int m = H; m < PB; ++m) f[m] = fma(-fj, lc[m - H], f[m]);
-    }
-  }
 }
 
 // Critical path of a panel step, run by a dedicated workgroup per front: rows k1..k1+31 of the panel are solved
@@ -767,22 +727,12 @@ __global__ __launch_bounds__(TB, 4) void front_leaf_kernel(
       AT[q * TP + r] = (q < kw && k1 + r <= nf) ? Fs[P(k1 + r, k0 + q)] : 0.0;
     }
     __syncthreads();
-    if (tid < TS) {
-      double* A = AT + tid;
-      double f[PB];
-#pragma unroll
-      for (int m = 0; m < PB; ++m) f[m] = A[m * TP];
-      trsm_row_lo(f, Lo, kw);
-#pragma unroll
-      for (int m = 0; m < PB; ++m) A[m * TP] = f[m];
-      if (k1 + tid <= nf) {
-        double* Lrow = F + (long long)ld * (k1 + tid) + k0;   // mirrored L for the backward sweep
-#pragma unroll
-        for (int m = 0; m < PB; ++m)
-          if (m < kw) Lrow[m] = f[m];
-      }
-    }
+    trsm_block64<true, true>(AT, TP, Lo, kw);      // all four waves, four lanes per row, straight from the packed factor
     __syncthreads();
+    for (int idx = tid; idx < TS * PB; idx += TB) {      // mirrored L for the backward sweep: row k1 + r, kw consecutive entries
+      const int r = idx / PB, m = idx % PB;
+      if (k1 + r <= nf && m < kw) F[(long long)ld * (k1 + r) + k0 + m] = AT[m * TP + r];
+    }
     // rank-kw update of the 64x64 trailing tile on the matrix cores (operand / result layout of front_step)
     typedef double v4f64 __attribute__((ext_vector_type(4)));
     const int lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
