@@ -298,6 +298,9 @@ def main():
             relc = float(abs(out["c_dot_Dz_final"] - gz["c_dot_Dz"][-1]) / abs(gz["c_dot_Dz"][-1]))
             out["parity"] = {"z_rel_l2_vs_oracle": relz, "c_dot_Dz_rel_vs_oracle": relc, "tolerance": 1e-10,
                              "oracle_newton_steps": int(gz["its"].sum()), "fixture": os.path.basename(gold)}
+            if "z_centre" in gz.files:       # the oracle's end point polished to the exact centre (tests/golden/polish_centre.py)
+                zc = gz["z_centre"].reshape(-1, order="F")
+                out["parity"]["z_rel_l2_vs_oracle_centre"] = float(np.linalg.norm(z_final - zc) / np.linalg.norm(zc))
             if not (relz < 1e-8 and relc < 1e-8):
                 print(json.dumps(out))
                 raise SystemExit("bench.py: the timed solve does not reproduce the oracle's z (rel l2 %.3e)" % relz)

@@ -438,21 +438,36 @@ def test_all_golden_files_are_covered():
     assert have == want
 
 
+# Newton on the finest level stops on stagnation of the objective (oracle stopping_exact), which resolves the centre of the last
+# t only up to the last step NOT taken; whether that step is taken hangs on the rounding of an objective of size 1e9.  In 2-D
+# both sides end within 3e-13 of the exact centre; in 3-D (fem3d L=4) the oracle stops 2.0e-10 short (1.2e-11 in u, 2.9e-10 in
+# the slack) and the HIP path 1.9e-13 (tests/golden/polish_centre.py, profiles/r2_fem3d_L4_centre.txt).  So the end points are
+# compared at the stop rule's resolution, and the HIP end point at 1e-11 with the oracle's EXACT centre `z_centre` (the oracle end
+# point polished by Newton steps whose gradient is evaluated in 80-bit extended precision -- oracle code only).
+LARGE_END_POINT_TOL = {"fem2d": ZTOL, "fem3d": 5e-10}
+LARGE_CENTRE_TOL = 1e-11
+
+
 @pytest.mark.parametrize("kind,L,p", LARGE_CASES)
 def test_headline_sizes_match_oracle_goldens(M, kind, L, p):
     """BASELINE.json configs at full size -- fem2d L=7 (the bench workload, p = 1 and 1.5) and fem3d L=4 -- against
-    z of the CPU oracle on the same mesh (tests/golden/make_golden_large.py; minutes of host time per case, so the
-    GPU box reads the committed vectors).  Bar: relative l2 <= 1e-10 (BASELINE.json north_star); the reference's
-    own two implementations differ by 3.3e-13 in the sup norm at L=7 (docs/src/guide.md:252).  Measured: 7.0e-13 (p = 1, 466
-    Newton steps here against 527 in the oracle: different kappa histories, same end point), 2.5e-13 (p = 1.5)."""
+    z of the CPU oracle on the same mesh (tests/golden/make_golden_large.py; minutes to hours of host time per case, so the
+    GPU box reads the committed vectors).  Bar: relative l2 <= 1e-10 (BASELINE.json north_star) against the oracle's exact
+    centre of t_final for every case, and against the oracle's own end point wherever its stop rule resolves that well (2-D);
+    the reference's own two implementations differ by 3.3e-13 in the sup norm at L=7 (docs/src/guide.md:252).
+    Measured to the end point / to the centre: fem2d p = 1 7.0e-13 / see log (466 Newton steps here against 527 in the oracle:
+    different kappa histories, same end point), p = 1.5 2.5e-13, fem3d 2.0e-10 / 1.9e-13."""
     gold = np.load(os.path.join(HERE, "golden", "large_%s_L%d_p%s.npz" % (kind, L, str(p).replace(".", "_"))))
     sol = getattr(M, kind + "_mpi_solve")(L=L, p=p)
     z = M.mpi_to_native(sol).z
     assert z.shape == gold["z"].shape
-    err = rel(z, gold["z"])
-    print("%s L=%d p=%g: rel l2 %.3e  sup %.3e  newton %d (oracle %d)" % (
-        kind, L, p, err, np.abs(z - gold["z"]).max(), int(sol.SOL_main["its"].sum()), int(gold["its"].sum())))
-    assert err < ZTOL
+    err, err_centre = rel(z, gold["z"]), rel(z, gold["z_centre"])
+    print("%s L=%d p=%g: rel l2 to the oracle end point %.3e (u %.3e), to the exact centre %.3e (oracle itself %.3e)  newton %d "
+          "(oracle %d)" % (kind, L, p, err, rel(z[:, 0], gold["z"][:, 0]), err_centre, float(gold["oracle_end_point_to_centre"]),
+                           int(sol.SOL_main["its"].sum()), int(gold["its"].sum())))
+    assert err_centre < LARGE_CENTRE_TOL
+    assert err < LARGE_END_POINT_TOL[kind]
+    assert rel(z[:, 0], gold["z"][:, 0]) < ZTOL                  # the solution component u: 1e-10 in every case
     assert np.allclose(sol.SOL_main["ts"][-1], gold["ts"][-1], rtol=1e-12)
     assert abs(sol.SOL_main["c_dot_Dz"][-1] - gold["c_dot_Dz"][-1]) <= 1e-9 * abs(gold["c_dot_Dz"][-1])
 
