@@ -121,6 +121,26 @@ def test_reference_sparse_algebra_kats(M):
     assert np.allclose(reg.to_scipy().toarray(), An.T @ An + 0.01 * np.eye(2), rtol=0, atol=1e-15)
 
 
+def test_operator_transpose_and_weighted_products(M):
+    """test/test_transpose_only.jl:45,85,129 (D_dx', hcat(D_dx, Z)' and D0' * spdiagm(w .* y) on fem1d L=2, 1e-12) and
+    test/test_partitions.jl:104 (D' * spdiagm(w) * D on fem1d L=3, 1e-10), through the library's device sparse types."""
+    g, gn = M.fem1d_mpi(2), M.fem1d(2)
+    n = len(gn.w)
+    Dn = sp.csr_matrix(gn.operators["dx"])
+    D = g.operators["dx"]
+    assert abs(D.T.to_scipy() - Dn.T).max() < 1e-12                                   # Test 1
+    D0, D0n = M.hcat(D, M.amgb_zeros(D, n, n)), sp.hstack([Dn, sp.csr_matrix((n, n))]).tocsr()
+    assert D0.shape == (n, 2 * n) and abs(D0.T.to_scipy() - D0n.T).max() < 1e-12      # Test 2
+    foo = M.amgb_diag(D, g.w * M.HPCVector(np.full(n, 0.5)))
+    tmp = D0.T @ foo                                                                  # Test 3
+    assert tmp.shape == (2 * n, n) and abs(tmp.to_scipy() - D0n.T @ sp.diags(gn.w * 0.5)).max() < 1e-12
+    g3, g3n = M.fem1d_mpi(3), M.fem1d(3)
+    D3, D3n = g3.operators["dx"], sp.csr_matrix(g3n.operators["dx"])
+    DtwD = D3.T @ (M.amgb_diag(D3, g3.w) @ D3)
+    want = (D3n.T @ sp.diags(g3n.w) @ D3n).toarray()
+    assert np.linalg.norm(DtwD.to_scipy().toarray() - want) < 1e-10
+
+
 def test_vector_ops(M):
     rng = np.random.default_rng(5)
     for n in (1, 63, 64, 65, 100003):
