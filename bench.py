@@ -223,6 +223,7 @@ def main():
             dist.barrier()
 
     fence()
+    comm0 = backend.comm_stats() if sharded else None
     t0 = time.perf_counter()
     sols = [one_solve() for _ in range(args.steps)]
     backend.synchronize()
@@ -231,6 +232,7 @@ def main():
     elapsed = max_over_ranks(elapsed, dist, "cpu" if args.rehearse_one_gpu else "cuda")
     if dist is not None:
         dist.barrier()
+    comm1 = backend.comm_stats() if sharded else None
     z_final = A.get_z()          # collective on a sharded context: every rank calls it
 
     newton_steps = int(sum(int(s["its"].sum()) for s in sols))
@@ -277,8 +279,9 @@ def main():
             "config": {"workload": "fem2d p-Laplace L=%d p=%g (n=%d rows, N_L=%d Newton unknowns), amgb main phase, "
                                    "tol=sqrt(eps)" % (args.L, args.p, n, NL),
                        "parallelism": "single GPU" if world == 1 else
-                       ("one solve, row-block sharded x%d (RCCL allreduce of gradient / Hessian values / separator Schur "
-                        "complements; factorisation split by nested-dissection subtrees, top replicated)" % world
+                       ("one solve, row-block sharded x%d (factorisation split by subtrees that follow the row blocks, top "
+                        "replicated; RCCL allreduce of the gradient, of the subtree roots' Schur complements + the Hessian "
+                        "entries among separator unknowns, and of the assembled step)" % world
                         if sharded else "replicas x%d (independent solves, not sharded)" % world)},
             "total_solve_s": elapsed / args.steps, "setup_s": t_setup,
             "total_solve_s_incl_setup": t_setup + elapsed / args.steps,
@@ -305,7 +308,12 @@ def main():
                 print(json.dumps(out))
                 raise SystemExit("bench.py: the timed solve does not reproduce the oracle's z (rel l2 %.3e)" % relz)
         if sharded:
-            out["allreduce"] = backend.comm_stats()
+            st = {k: comm1[k] - comm0[k] for k in comm1}      # the timed solves only
+            info = A.chol_info()
+            out["allreduce"] = dict(st, per_newton_step={"collectives": st["calls"] / max(newton_steps, 1),
+                                                         "bytes": st["bytes"] / max(newton_steps, 1)},
+                                    hessian_values_stay_on_their_rank=info["values_local"],
+                                    factorisation_split_over=info["split_world"])
         if args.probe_L > 0 and world == 1:      # N=1 only, like the CPU baseline
             # secondary evidence for the bandwidth-shaped kernels: the same kernels on the
             # workload mesh (cache resident, launch bound) and on a mesh whose rotating working set exceeds the 256 MiB

@@ -150,6 +150,10 @@ int mgb_amg_level_size(mgb_amg a, int level, int* N, int* nnz_lower);
  * on a sharded context (1 = replicated: single GPU, or a world the tree cannot be split into), doubles exchanged per Newton
  * system (subtree-root Schur complements + the assembled solution), kernel launches per Newton system */
 int mgb_amg_chol_info(mgb_amg a, int level, int* split_world, double* exchange_doubles, int* launches);
+/* *yes = 1 if the subtrees of the split follow the row partition: a rank's Hessian values are then used where they were
+ * computed, only the entries among separator unknowns are summed (inside the Schur-complement collective, counted in
+ * exchange_doubles), and the allreduce of all nnz values per Newton step is gone (MGB_RANK_ALIGNED=0 restores it) */
+int mgb_amg_chol_values_local(mgb_amg a, int level, int* yes);
 int mgb_amg_hessian_pattern(mgb_amg a, int level, int32_t* rowptr, int32_t* colidx);  /* lower triangle of R'HR */
 int mgb_amg_set_c(mgb_amg a, const double* c);     /* n x K row-major cost (f_grid) */
 int mgb_amg_set_z(mgb_amg a, const double* z);     /* S*n, [u; s] */
@@ -232,6 +236,17 @@ int mgb_hostchol_factor_solve(mgb_hostchol c, const double* lower_vals, const do
 int mgb_hostchol_partition(mgb_hostchol c, int world, int* split_world, int cap, int* nnodes, int* owner);
 int mgb_hostchol_factor_solve_dist(mgb_hostchol c, int rank, int world, mgb_allreduce_fn fn, void* user,
                                    const double* lower_vals, const double* g, double* x);
+/* Reduce-to-owner for the matrix entries (row (e); the reference's MUMPS takes distributed entries the same way): analysed
+ * with the row partition of a `world`-rank job (`p` = the UNSHARDED plan, K = rows of D, block = rows per element), the top
+ * log2(world) levels of the dissection follow the row blocks, subtree r is the interior of rank r's rows and all its matrix
+ * entries are complete on rank r.  rank_aligned: *aligned = 1 if that held for every split (else the caller must sum the
+ * values over the ranks as before), *top_values = entries among separator unknowns, the only ones that still travel.
+ * factor_solve_dist_local: as factor_solve_dist, but `local_lower_vals` holds only THIS rank's row-block contributions
+ * (mgb_plan_eval_host of its shard); the top entries ride in the Schur-complement collective.  g is replicated. */
+int mgb_plan_hostchol_create_ranked(mgb_plan p, int dim, int K, int world, int block, mgb_hostchol* out);
+int mgb_hostchol_rank_aligned(mgb_hostchol c, int world, int* aligned, int* top_values);
+int mgb_hostchol_factor_solve_dist_local(mgb_hostchol c, int rank, int world, mgb_allreduce_fn fn, void* user,
+                                         const double* local_lower_vals, const double* g, double* x);
 /* host-only: the nested-dissection elimination tree of this level's pattern in postorder (children first):
  * own size, front size and parent (-1 = root) of the first min(cap, *nnodes) nodes */
 int mgb_plan_chol_tree(mgb_plan p, int dim, int cap, int* nnodes, int* ns, int* nf, int* parent);

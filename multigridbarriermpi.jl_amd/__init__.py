@@ -815,10 +815,12 @@ class AMG:
 
     def chol_info(self, l=None):
         """Device factorisation of level l (default finest): ranks it is split over, doubles exchanged and launches per
-        Newton system."""
+        Newton system, and whether the Hessian values stay on the rank that computed them (subtrees = row blocks)."""
         sw, ex, la = C.c_int(), C.c_double(), C.c_int()
         call("mgb_amg_chol_info", self.handle, self.L - 1 if l is None else int(l), C.byref(sw), C.byref(ex), C.byref(la))
-        return dict(split_world=sw.value, exchange_doubles=ex.value, launches=la.value)
+        vl = C.c_int()
+        call("mgb_amg_chol_values_local", self.handle, self.L - 1 if l is None else int(l), C.byref(vl))
+        return dict(split_world=sw.value, exchange_doubles=ex.value, launches=la.value, values_local=bool(vl.value))
 
     def hessian_pattern(self, l):
         N, nz = self.level_size(l)

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "mgb_amg_local_rows": [H, c_int_p, c_int_p, c_int_p],
     "mgb_amg_prepare": [H, C.c_int],
     "mgb_amg_chol_info": [H, C.c_int, c_int_p, c_dbl_p, c_int_p],
+    "mgb_amg_chol_values_local": [H, C.c_int, c_int_p],
     "mgb_amg_level_size": [H, C.c_int, c_int_p, c_int_p],
     "mgb_amg_hessian_pattern": [H, C.c_int, c_i32_p, c_i32_p],
     "mgb_amg_set_c": [H, c_dbl_p],
@@ -117,6 +118,9 @@ PROTOTYPES = {
     "mgb_hostchol_factor_solve": [H, c_dbl_p, c_dbl_p, c_dbl_p],
     "mgb_hostchol_partition": [H, C.c_int, c_int_p, C.c_int, c_int_p, c_int_p],
     "mgb_hostchol_factor_solve_dist": [H, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p, c_dbl_p, c_dbl_p, c_dbl_p],
+    "mgb_plan_hostchol_create_ranked": [H, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(H)],
+    "mgb_hostchol_rank_aligned": [H, C.c_int, c_int_p, c_int_p],
+    "mgb_hostchol_factor_solve_dist_local": [H, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p, c_dbl_p, c_dbl_p, c_dbl_p],
     "mgb_plan_chol_tree": [H, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p],
     "mgb_chol_selftest": [C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],
 }

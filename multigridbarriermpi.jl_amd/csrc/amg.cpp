@@ -52,6 +52,18 @@ void shard_rows(int rank, int world, int n, int block, int* r0, int* r1) {
   *r1 = (int)(nel * (rank + 1) / world) * block;
 }
 
+std::vector<unsigned long long> dof_rank_masks(const Csr& B, int n, int K, int world, int block) {
+  if (world > 64) return {};
+  std::vector<unsigned long long> m((size_t)B.cols, 0ull);
+  for (int rk = 0; rk < world; ++rk) {
+    int r0, r1;
+    shard_rows(rk, world, n, block, &r0, &r1);
+    for (long long row = (long long)r0 * K; row < (long long)r1 * K; ++row)
+      for (int k = B.rowptr[row]; k < B.rowptr[row + 1]; ++k) m[B.colidx[k]] |= 1ull << rk;
+  }
+  return m;
+}
+
 Csr shard_dstack(const Csr& Dstack, int n, int S, int K, int r0, int r1) {
   const int nl = r1 - r0;
   std::vector<int> map((size_t)n * S, -1);      // z index sv*n + node -> sv*nl + (node - r0)
@@ -458,7 +470,11 @@ Amg::Level& Amg::level(int l) {
   if (lv.built) return lv;
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
   lv.plan = build_level_plan(geo_, spec_, dstack_host_, l, P_);
-  if (ctx_.world > 1) lv.plan = shard_level_plan(lv.plan, ng_, S_, P_.K, P_.nY(), r0_, r0_ + n_);
+  if (ctx_.world > 1) {
+    std::vector<unsigned long long> mask = dof_rank_masks(lv.plan.B, ng_, P_.K, ctx_.world, geo_.block);
+    lv.plan = shard_level_plan(lv.plan, ng_, S_, P_.K, P_.nY(), r0_, r0_ + n_);
+    lv.plan.rank_mask = std::move(mask);
+  }
   const double t_up = now_s();
   lv.R.upload(lv.plan.R);
   lv.B.upload(lv.plan.B);
@@ -492,7 +508,10 @@ void Amg::ensure_chol(Level& lv) {
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
   static const bool vt = std::getenv("MGB_VERBOSE_SETUP") != nullptr;
   double t0 = now_s();
-  lv.chol.analyze(lv.plan.Apat, lv.plan.coords.data(), geo_.dim);
+  // MGB_RANK_ALIGNED=0: geometric tree + Hessian values summed over the ranks (the scheme before; kept for A/B runs)
+  static const bool aligned_on = !(std::getenv("MGB_RANK_ALIGNED") && std::atoi(std::getenv("MGB_RANK_ALIGNED")) == 0);
+  const bool ranked = aligned_on && ctx_.world > 1 && (int)lv.plan.rank_mask.size() == lv.plan.N;
+  lv.chol.analyze(lv.plan.Apat, lv.plan.coords.data(), geo_.dim, 64, ranked ? lv.plan.rank_mask.data() : nullptr, ctx_.world);
   if (vt) std::fprintf(stderr, "[mgb setup] chol analyze                %.3f s\n", now_s() - t0);
   t0 = now_s();
   lv.gchol.build(lv.chol, &ctx_);      // sharded context: split by subtrees (gpuchol.hpp)
@@ -683,6 +702,12 @@ double Amg::dev_f0(Level& lv, const double* s_dev, double t, double* parts, cons
 
 // gradient at s into g_out (device); returns |g|_2 (non-finite if any entry is)
 // Hessian values of the point whose Dz is dz: Y = w F2(Dz), avals = T vec(Y) (summed over the row blocks when sharded)
+bool Amg::values_stay_local(Level& lv) {
+  if (ctx_.world <= 1 || host_solve_) return false;
+  ensure_chol(lv);
+  return lv.gchol.values_local();
+}
+
 void Amg::enqueue_f2_assemble(Level& lv, const double* dz, SolveStats& st) {
   timer_.begin(ctx_.stream, KC_F2, (double)n_ * (P_.K + 1 + P_.nY()) * 8);
   launch_barrier_f2(ctx_.stream, n_, P_, dz, w_.p, Y_.p);
@@ -690,7 +715,9 @@ void Amg::enqueue_f2_assemble(Level& lv, const double* dz, SolveStats& st) {
   timer_.begin(ctx_.stream, KC_ASSEMBLE, csr_bytes(lv.T.view, false));
   launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
   timer_.end(ctx_.stream);
-  ctx_.allreduce_sum(lv.avals.p, lv.plan.Apat.nnz());      // sharded: every rank then factors the same replicated matrix
+  // sharded: summed over the row blocks, unless the factorisation's subtrees follow the row partition -- then a rank's own
+  // contributions are all its subtree needs and the few entries among separator unknowns travel inside the solve
+  if (!values_stay_local(lv)) ctx_.allreduce_sum(lv.avals.p, lv.plan.Apat.nnz());
   st.n_f2++;
 }
 
@@ -1201,7 +1228,7 @@ bool Amg::solve_device(int l, const double* avals, const double* g, double* nste
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   lv.avals.upload(avals, lv.plan.Apat.nnz());
   lv.g_trial.upload(g, lv.plan.N);
-  lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g_trial.p, lv.nstep.p);
+  lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g_trial.p, lv.nstep.p, nullptr, false, /*values_summed=*/true);
   lv.flag_armed = false;      // this path leaves the flag as the factorisation set it
   hip_check(hipMemcpyAsync(h_flag_.p, lv.gchol.fail_flag(), sizeof(int), hipMemcpyDeviceToHost, ctx_.stream), "D2H flag");
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");

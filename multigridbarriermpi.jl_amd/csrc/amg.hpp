@@ -123,11 +123,16 @@ struct LevelPlan {
   Csr Apat;     // N x N lower-triangle pattern of R'HR (vals unused)
   Csr T;        // nnz(Apat) x (n nY)
   std::vector<double> coords;  // N x dim
+  std::vector<unsigned long long> rank_mask;      // sharded plans: dof_rank_masks of the unsharded B (else empty)
 };
 
 // Row-block shard [r0, r1) of the node rows (element aligned): local rows of B / R, matching columns of BT / T;
 // N, Apat and coords stay global (the Newton unknowns and the factorisation are replicated on every rank).
 void shard_rows(int rank, int world, int n, int block, int* r0, int* r1);
+// per Newton unknown (column of the UNSHARDED B): bit r set if a row of rank r's row block touches it; empty if world > 64.
+// The elimination tree of a sharded job is built along these (MfChol::analyze), so that the matrix entries of a rank's
+// subtree are complete on that rank and only separator entries are summed over the ranks.
+std::vector<unsigned long long> dof_rank_masks(const Csr& B, int n, int K, int world, int block);
 LevelPlan shard_level_plan(const LevelPlan& full, int n, int S, int K, int nY, int r0, int r1);
 Csr shard_dstack(const Csr& Dstack, int n, int S, int K, int r0, int r1);
 
@@ -214,6 +219,7 @@ class Amg {
   const BarrierParams& params() const { return P_; }
   // device factorisation of level l: ranks it is split over (1 = replicated), doubles exchanged per solve, launches
   void chol_info(int l, int* split_world, double* exchange_doubles, int* launches);
+  bool chol_values_local(int l) { return values_stay_local(level(l)); }
 
   // problem data: c is n x K row-major, z is the S*n vector [u; s]
   void set_c(const double* c_host);
@@ -284,6 +290,8 @@ class Amg {
   // gradient from the Dz of the point; returns |g|.  pre != nullptr: also assembles the point's Hessian values behind it
   double dev_f1(Level& lv, const double* dz, double t, double* g_out, SolveStats* st = nullptr, const double** pre = nullptr);
   void enqueue_f2_assemble(Level& lv, const double* dz, SolveStats& st);
+  // sharded + device factorisation whose subtrees follow the row partition: Hessian values are NOT summed over the ranks
+  bool values_stay_local(Level& lv);
   struct EventHolder {      // owns the event the host waits on for |g|
     hipEvent_t e = nullptr;
     ~EventHolder() {

@@ -722,6 +722,12 @@ int mgb_amg_chol_info(mgb_amg a, int level, int* split_world, double* exchange_d
     a->amg->chol_info(level, split_world, exchange_doubles, launches);
   });
 }
+int mgb_amg_chol_values_local(mgb_amg a, int level, int* yes) {
+  return guard([&] {
+    need(a && yes && level >= 0 && level < a->amg->L(), "level out of range");
+    *yes = a->amg->chol_values_local(level) ? 1 : 0;
+  });
+}
 int mgb_amg_level_size(mgb_amg a, int level, int* N, int* nnz_lower) {
   return guard([&] {
     need(a && level >= 0 && level < a->amg->L(), "level out of range");
@@ -1006,6 +1012,27 @@ int mgb_plan_hostchol_create(mgb_plan p, int dim, mgb_hostchol* out) {
     *out = c;
   });
 }
+int mgb_plan_hostchol_create_ranked(mgb_plan p, int dim, int K, int world, int block, mgb_hostchol* out) {
+  return guard([&] {
+    need(p && out && dim >= 1 && dim <= 3 && K >= 1 && world >= 1, "hostchol_create_ranked: bad arguments");
+    auto* c = new mgb_hostchol_s;
+    try {
+      const std::vector<unsigned long long> mask = dof_rank_masks(p->plan.B, p->n, K, world, block);
+      c->ch.analyze(p->plan.Apat, p->plan.coords.data(), dim, 64, mask.empty() ? nullptr : mask.data(), world);
+    } catch (...) {
+      delete c;
+      throw;
+    }
+    *out = c;
+  });
+}
+int mgb_hostchol_rank_aligned(mgb_hostchol c, int world, int* aligned, int* top_values) {
+  return guard([&] {
+    need(c && aligned, "hostchol_rank_aligned: null argument");
+    *aligned = c->ch.rank_aligned(world) ? 1 : 0;
+    if (top_values) *top_values = *aligned ? (int)c->ch.top_value_indices(c->ch.partition(world)).size() : 0;
+  });
+}
 int mgb_hostchol_destroy(mgb_hostchol c) {
   return guard([&] { delete c; });
 }
@@ -1046,6 +1073,21 @@ int mgb_hostchol_factor_solve_dist(mgb_hostchol c, int rank, int world, mgb_allr
       if (rc != 0) throw InternalError("mgb: allreduce callback failed with code " + std::to_string(rc));
     };
     if (!c->ch.factor_solve_dist(lower_vals, x, part, rank, ar)) throw NumericError("MfChol: matrix is not positive definite");
+  });
+}
+
+int mgb_hostchol_factor_solve_dist_local(mgb_hostchol c, int rank, int world, mgb_allreduce_fn fn, void* user,
+                                         const double* local_lower_vals, const double* g, double* x) {
+  return guard([&] {
+    need(c && local_lower_vals && g && x && world >= 2 && rank >= 0 && rank < world && fn, "hostchol_factor_solve_dist_local: bad arguments");
+    CholPartition part = c->ch.partition(world);
+    if (x != g) std::copy(g, g + c->ch.size(), x);
+    auto ar = [&](double* ptr, long long count) {
+      const int rc = fn(user, ptr, count);
+      if (rc != 0) throw InternalError("mgb: allreduce callback failed with code " + std::to_string(rc));
+    };
+    if (!c->ch.factor_solve_dist(local_lower_vals, x, part, rank, ar, /*vals_local=*/true))
+      throw NumericError("MfChol: matrix is not positive definite");
   });
 }
 

@@ -907,6 +907,17 @@ __global__ __launch_bounds__(256) void schur_unpack_kernel(const RootXchg* __res
   }
 }
 
+// values_local(): the matrix entries of the top nodes, gathered behind the Schur complements and scattered back summed
+__global__ __launch_bounds__(256) void vals_pack_kernel(int n, const int* __restrict__ idx, const double* __restrict__ vals,
+                                                        double* __restrict__ xb) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) xb[i] = vals[idx[i]];
+}
+
+__global__ __launch_bounds__(256) void vals_unpack_kernel(int n, const int* __restrict__ idx, const double* __restrict__ xb,
+                                                          double* __restrict__ vals) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) vals[idx[i]] = xb[i];
+}
+
 // x of the unknowns this rank is responsible for (its subtree; rank 0 also the top), zeros elsewhere, + the pivot flag
 __global__ __launch_bounds__(256) void xsol_pack_kernel(int n, const int* __restrict__ own, const double* __restrict__ x,
                                                         const int* __restrict__ fail, double* __restrict__ xs) {
@@ -1243,7 +1254,13 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
       if (part_.owner[t] == my_rank || (part_.owner[t] < 0 && my_rank == 0))
         for (int k = 0; k < nodes[t].ns; ++k) own[sym.perm_[nodes[t].first + k]] = 1;
     d_own_orig_ = upload(own);
-    ck(hipMalloc((void**)&d_xchg_, std::max<long long>(xchg_doubles_, 1) * sizeof(double)), "hipMalloc xchg");
+    vals_local_ = sym.rank_aligned(part_.world);
+    if (vals_local_) {
+      const std::vector<int> top_idx = sym.top_value_indices(part_);
+      ntop_vals_ = (int)top_idx.size();
+      d_top_idx_ = upload(top_idx);
+    }
+    ck(hipMalloc((void**)&d_xchg_, std::max<long long>(xchg_doubles_ + ntop_vals_, 1) * sizeof(double)), "hipMalloc xchg");
     allocs_.push_back(d_xchg_);
     ck(hipMalloc((void**)&d_xsol_, (size_t)(n_ + 1) * sizeof(double)), "hipMalloc xsol");
     allocs_.push_back(d_xsol_);
@@ -1280,7 +1297,8 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
 // The whole chain is launch-bound (83 dependent launches at fem2d L=7), so it is captured once per
 // (values, rhs, solution) pointer triple into a hipGraph and replayed with ONE host call per Newton step; the
 // event-timed and phase-stamped variants (KernelTimer, MGB_CHOL_PROF) and MGB_CHOL_GRAPH=0 use plain launches.
-void GpuChol::factor_solve(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm, bool flag_armed) {
+void GpuChol::factor_solve(hipStream_t st, double* d_vals, const double* d_b, double* d_x, KernelTimer* tm, bool flag_armed,
+                           bool values_summed) {
   if (n_ == 0) return;
   static const bool use_graph = [] {
     const char* e = std::getenv("MGB_CHOL_GRAPH");
@@ -1290,7 +1308,7 @@ void GpuChol::factor_solve(hipStream_t st, const double* d_vals, const double* d
   // to leave garbage in the flag when another library used the device between replays)
   if (!flag_armed) ck(hipMemsetAsync(d_fail_, 0, sizeof(int), st), "memset flag");
   if (part_.split()) {      // two collectives inside: plain launches, no graph
-    factor_solve_split(st, d_vals, d_b, d_x, tm);
+    factor_solve_split(st, d_vals, d_b, d_x, tm, values_summed);
     return;
   }
   if (!use_graph || tm || d_prof_) {
@@ -1385,14 +1403,21 @@ void GpuChol::enqueue_chain(hipStream_t st, const double* d_vals, const double* 
   ck(hipGetLastError(), "chain launches");
 }
 
-void GpuChol::factor_solve_split(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm) {
+void GpuChol::factor_solve_split(hipStream_t st, double* d_vals, const double* d_b, double* d_x, KernelTimer* tm, bool values_summed) {
   int nprof = 0;
+  const bool ride = vals_local_ && !values_summed;
+  const int ntop = ride ? ntop_vals_ : 0;
   enqueue_forward(st, plan_, d_vals, d_b, tm, nprof);                    // this rank's subtree
   const dim3 xg(nroots_, std::max(1, std::min(64, max_root_nb_)));
   hipLaunchKernelGGL(schur_pack_kernel, xg, dim3(256), 0, st, d_roots_, d_fronts_, d_xchg_);
+  const int vgrid = std::max(1, std::min(1024, (ntop_vals_ + 255) / 256));
+  if (ride)      // this rank's partial sums of the top nodes' matrix entries ride along
+    hipLaunchKernelGGL(vals_pack_kernel, dim3(vgrid), dim3(256), 0, st, ntop_vals_, d_top_idx_, d_vals, d_xchg_ + xchg_doubles_);
   ck(hipGetLastError(), "schur pack");
-  ctx_->allreduce_sum(d_xchg_, xchg_doubles_);                           // every subtree root's Schur complement, everywhere
+  ctx_->allreduce_sum(d_xchg_, xchg_doubles_ + ntop);                    // every subtree root's Schur complement, everywhere
   hipLaunchKernelGGL(schur_unpack_kernel, xg, dim3(256), 0, st, d_roots_, d_xchg_, d_fronts_);
+  if (ride)
+    hipLaunchKernelGGL(vals_unpack_kernel, dim3(vgrid), dim3(256), 0, st, ntop_vals_, d_top_idx_, d_xchg_ + xchg_doubles_, d_vals);
   enqueue_forward(st, plan_top_, d_vals, d_b, tm, nprof);                // replicated top: same arithmetic on every rank
   enqueue_backward(st, plan_top_, d_x, tm);
   enqueue_backward(st, plan_, d_x, tm);

@@ -93,12 +93,18 @@ class GpuChol {
   // arithmetic as the unsplit factorisation.
   void build(const MfChol& sym, Ctx* ctx = nullptr);
   bool split() const { return part_.split(); }
-  double exchange_doubles() const { return (double)xchg_doubles_ + n_ + 1; }
+  // split AND the tree's top follows the row partition (MfChol::rank_aligned): factor_solve takes THIS rank's row-block
+  // contributions to the matrix entries -- the caller does not sum the values over the ranks; the entries of the top
+  // nodes ride in the Schur-complement collective and their sums are written back into d_vals.
+  bool values_local() const { return vals_local_; }
+  double exchange_doubles() const { return (double)xchg_doubles_ + ntop_vals_ + n_ + 1; }
   // d_x = A^{-1} d_b: d_vals = device lower-triangle values in the pattern order given to MfChol::analyze,
   // d_b / d_x device vectors in the ORIGINAL ordering (may alias).
   // flag_armed: the caller guarantees the pivot flag is zero (it re-arms it itself behind the chain): no memset launch
-  void factor_solve(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* timer = nullptr,
-                    bool flag_armed = false);
+  // d_vals is written only when values_local() (top entries <- their sums over the ranks)
+  // values_summed: d_vals already holds the sums over the ranks on every rank (a matrix handed in from outside)
+  void factor_solve(hipStream_t st, double* d_vals, const double* d_b, double* d_x, KernelTimer* timer = nullptr,
+                    bool flag_armed = false, bool values_summed = false);
   // the bare launch chain (no flag re-arm, no graph of its own): for callers that capture it into a larger graph together
   // with what follows the solve.  Not for split factorisations (their collectives cannot be captured).
   void enqueue_chain(hipStream_t st, const double* d_vals, const double* d_b, double* d_x);
@@ -116,13 +122,16 @@ class GpuChol {
   void enqueue_forward(hipStream_t st, const std::vector<HeightPlan>& plan, const double* d_vals, const double* d_b, KernelTimer* tm,
                        int& nprof);
   void enqueue_backward(hipStream_t st, const std::vector<HeightPlan>& plan, double* d_x, KernelTimer* tm);
-  void factor_solve_split(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm);
+  void factor_solve_split(hipStream_t st, double* d_vals, const double* d_b, double* d_x, KernelTimer* tm, bool values_summed);
   Ctx* ctx_ = nullptr;
   CholPartition part_;
   long long xchg_doubles_ = 0;
   RootXchg* d_roots_ = nullptr;
   int nroots_ = 0, max_root_nb_ = 0;
-  double* d_xchg_ = nullptr;      // Schur exchange buffer
+  double* d_xchg_ = nullptr;      // Schur exchange buffer (+ ntop_vals_ matrix entries of the top nodes behind it)
+  bool vals_local_ = false;
+  int ntop_vals_ = 0;
+  int* d_top_idx_ = nullptr;      // indices into d_vals of the entries assembled into the top nodes
   double* d_xsol_ = nullptr;      // n + 1: masked solution + pivot flag
   int* d_own_orig_ = nullptr;     // per unknown (original ordering): 1 if this rank contributes it to the assembled x
   struct GraphEntry {      // captured launch chain for one (values, rhs, solution) pointer triple

@@ -230,7 +230,8 @@ int MfChol::threads() { return hw_threads(); }
 // build their halves concurrently into private subtrees, which are then appended left, right, parent: the same postorder
 // the sequential recursion produces.
 int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const double* coords, int dim, int leaf,
-                  std::vector<int>& label, std::atomic<int>& next_label, Subtree& sub, int par_depth) {
+                  std::vector<int>& label, std::atomic<int>& next_label, Subtree& sub, int par_depth,
+                  const unsigned long long* mask, int rlo, int rhi) {
   std::vector<Node>& nodes_ = sub.nodes;      // shadows the member: this recursion only ever touches `sub`
   std::vector<std::vector<int>>& own = sub.own;
   // (`label` entries of dofs outside [lo, hi) may be rewritten concurrently by a sibling subtree: relaxed atomics; their
@@ -241,6 +242,28 @@ int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const do
     own.emplace_back(dofs.begin() + lo, dofs.begin() + hi);
     return (int)nodes_.size() - 1;
   };
+  std::vector<int> Ap, Bv, S;
+  const unsigned long long* cmask = nullptr;      // rank masks for the children (null: geometric dissection below here)
+  int rmid = rlo;
+  bool guided = false;
+  if (mask && rhi - rlo > 1) {
+    // sharded job, top of the tree: split by who touches the unknown (see analyze() in the header)
+    rmid = (rlo + rhi) / 2;
+    auto bits = [](int a, int b) { return (b >= 64 ? ~0ull : ((1ull << b) - 1)) & ~((1ull << a) - 1); };
+    const unsigned long long low = bits(rlo, rmid), high = bits(rmid, rhi);
+    for (int i = lo; i < hi; ++i) {
+      const int v = dofs[i];
+      ((mask[v] & high) == 0 ? Ap : (mask[v] & low) == 0 ? Bv : S).push_back(v);
+    }
+    if (Ap.empty() || Bv.empty()) {
+      align_failed_.store(true);      // a rank without interior unknowns: this subtree falls back to the geometry
+      Ap.clear(); Bv.clear(); S.clear();
+    } else {
+      guided = true;
+      cmask = mask;
+    }
+  }
+  if (!guided) {
   if (cnt <= leaf) return make_leaf();
   // widest axis
   int axis = 0;
@@ -303,7 +326,6 @@ int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const do
   for (int i = lo; i < midp; ++i) __atomic_store_n(&label[dofs[i]], tagA, __ATOMIC_RELAXED);
   for (int i = midp; i < hi; ++i) __atomic_store_n(&label[dofs[i]], tagB, __ATOMIC_RELAXED);
   // Ap / Bv: the two halves without the separator S (taken from one side)
-  std::vector<int> Ap, Bv, S;
   for (int i = lo; i < hi; ++i) {
     const int v = dofs[i];
     const bool inA = i < midp;
@@ -315,6 +337,7 @@ int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const do
     (sep ? S : (inA ? Ap : Bv)).push_back(v);
   }
   if (Ap.empty() || Bv.empty() || (int)S.size() * 2 > cnt) return make_leaf();  // S empty: disconnected halves, empty separator node
+  }      // !guided
   std::copy(Ap.begin(), Ap.end(), dofs.begin() + lo);
   std::copy(Bv.begin(), Bv.end(), dofs.begin() + lo + Ap.size());
   std::copy(S.begin(), S.end(), dofs.begin() + lo + Ap.size() + Bv.size());
@@ -322,8 +345,8 @@ int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const do
   int cl, cr;
   if (par_depth > 0 && cnt > 4096) {
     Subtree left, right;
-    std::thread worker([&] { build(dofs, lo, a_end, A, coords, dim, leaf, label, next_label, left, par_depth - 1); });
-    build(dofs, a_end, b_end, A, coords, dim, leaf, label, next_label, right, par_depth - 1);
+    std::thread worker([&] { build(dofs, lo, a_end, A, coords, dim, leaf, label, next_label, left, par_depth - 1, cmask, rlo, rmid); });
+    build(dofs, a_end, b_end, A, coords, dim, leaf, label, next_label, right, par_depth - 1, cmask, rmid, rhi);
     worker.join();
     auto append = [&](Subtree& part) {
       const int off = (int)nodes_.size();
@@ -338,8 +361,8 @@ int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const do
     cl = append(left);
     cr = append(right);
   } else {
-    cl = build(dofs, lo, a_end, A, coords, dim, leaf, label, next_label, sub, 0);
-    cr = build(dofs, a_end, b_end, A, coords, dim, leaf, label, next_label, sub, 0);
+    cl = build(dofs, lo, a_end, A, coords, dim, leaf, label, next_label, sub, 0, cmask, rlo, rmid);
+    cr = build(dofs, a_end, b_end, A, coords, dim, leaf, label, next_label, sub, 0, cmask, rmid, rhi);
   }
   nodes_.emplace_back();
   own.emplace_back(S);
@@ -350,7 +373,7 @@ int MfChol::build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const do
   return t;
 }
 
-void MfChol::analyze(const Csr& Ain, const double* coords, int dim, int leaf_size) {
+void MfChol::analyze(const Csr& Ain, const double* coords, int dim, int leaf_size, const unsigned long long* rank_mask, int world) {
   if (const char* e = std::getenv("MGB_LEAF")) leaf_size = std::max(8, std::atoi(e));      // tuning knob
   if (Ain.rows != Ain.cols) throw ArgError("MfChol: matrix not square");
   n_ = Ain.rows;
@@ -395,7 +418,12 @@ void MfChol::analyze(const Csr& Ain, const double* coords, int dim, int leaf_siz
   Subtree whole;
   int par_depth = 0;
   while ((1 << par_depth) < hw_threads()) ++par_depth;
-  if (n_ > 0) roots_.push_back(build(dofs, 0, n_, A, coords, dim, leaf_size, label, next_label, whole, par_depth));
+  const bool ranked = rank_mask && world > 1 && world <= 64 && (world & (world - 1)) == 0;
+  align_failed_.store(false);
+  if (n_ > 0)
+    roots_.push_back(build(dofs, 0, n_, A, coords, dim, leaf_size, label, next_label, whole, par_depth, ranked ? rank_mask : nullptr,
+                           0, ranked ? world : 1));
+  aligned_world_ = (ranked && !align_failed_.load()) ? world : 1;
   nodes_ = std::move(whole.nodes);
   std::vector<std::vector<int>>& own = whole.own;
   phase("nested dissection");
@@ -480,6 +508,7 @@ void MfChol::analyze(const Csr& Ain, const double* coords, int dim, int leaf_siz
       a_idx_[t].push_back(k);
       a_pos_[t].push_back(pos_in(nd, i) + nd.nf() * (j - nd.first));
     }
+  a_nnz_ = Ain.rowptr[n_];
   phase("assembly map");
   // the host fronts (106 MB at fem2d L=7) are only touched by the HOST numeric factorisation: allocated on its first use
   fronts_total_ = total;
@@ -623,15 +652,29 @@ CholPartition MfChol::partition(int world) const {
   return part;
 }
 
-bool MfChol::factor_solve_dist(const double* vals, double* b, const CholPartition& part, int rank, const Allreduce& allreduce) {
+std::vector<int> MfChol::top_value_indices(const CholPartition& part) const {
+  std::vector<int> idx;
+  if (!part.split()) return idx;
+  for (size_t t = 0; t < nodes_.size(); ++t)
+    if (part.owner[t] < 0) idx.insert(idx.end(), a_idx_[t].begin(), a_idx_[t].end());
+  return idx;
+}
+
+bool MfChol::factor_solve_dist(const double* vals_in, double* b, const CholPartition& part, int rank, const Allreduce& allreduce,
+                               bool vals_local) {
   if (n_ == 0) return true;
   const int nn = (int)nodes_.size();
+  if (vals_local && !(part.split() && rank_aligned(part.world)))
+    throw ArgError("MfChol: rank-local values need a tree whose top follows the row partition (analyze with rank masks)");
+  const double* vals = vals_in;
   if (!part.split()) {
     const bool ok = factor(vals);
     if (ok) solve(b);
     return ok;
   }
   if ((int)part.owner.size() != nn || rank < 0 || rank >= part.world) throw ArgError("MfChol: partition does not match the tree");
+  const std::vector<int> top_idx = vals_local ? top_value_indices(part) : std::vector<int>();
+  std::vector<double> vals_sum;      // vals_local: this rank's values with the top entries replaced by their sums over the ranks
   if (fronts_.size() != fronts_total_) fronts_.assign(fronts_total_, 0.0);
   bool ok = true;
   std::vector<double> y(n_), y0(n_);
@@ -651,8 +694,10 @@ bool MfChol::factor_solve_dist(const double* vals, double* b, const CholPartitio
     const long long nb = (long long)nodes_[part.roots[j]].bdry.size();
     xoff[j + 1] = xoff[j] + nb * (nb + 1) / 2;
   }
-  std::vector<double> xb((size_t)xoff[part.world] + top_dofs.size(), 0.0);
+  const size_t voff = (size_t)xoff[part.world] + top_dofs.size();
+  std::vector<double> xb(voff + top_idx.size(), 0.0);
   xb[0] = ok ? 0.0 : 1.0;
+  for (size_t q = 0; q < top_idx.size(); ++q) xb[voff + q] = vals[top_idx[q]];      // partial sums of the top entries
   if (ok) {
     const Node& ch = nodes_[part.roots[rank]];
     const int cf = ch.nf(), cs = ch.ns, nb = (int)ch.bdry.size();
@@ -664,6 +709,11 @@ bool MfChol::factor_solve_dist(const double* vals, double* b, const CholPartitio
   }
   allreduce(xb.data(), (long long)xb.size());
   if (xb[0] != 0.0) return false;      // some rank hit a non-positive pivot
+  if (vals_local) {
+    vals_sum.assign(vals, vals + a_nnz_);
+    for (size_t q = 0; q < top_idx.size(); ++q) vals_sum[top_idx[q]] = xb[voff + q];
+    vals = vals_sum.data();
+  }
   for (int j = 0; j < part.world; ++j) {
     Node& ch = nodes_[part.roots[j]];
     const int cf = ch.nf(), cs = ch.ns, nb = (int)ch.bdry.size();

@@ -33,7 +33,15 @@ class MfChol {
   // pattern: CSR pattern holding every unordered pair (i,j) exactly once, e.g. the lower triangle
   // (values ignored); coords: N x dim (row-major) dof positions
   // used only to choose the ordering (any values give a correct factorization).
-  void analyze(const Csr& pattern, const double* coords, int dim, int leaf_size = 64);
+  // rank_mask (nullable, N entries) / world: sharded jobs.  Bit r of rank_mask[i] says that rows of rank r's row block
+  // touch unknown i.  The top log2(world) levels of the dissection then follow the ROW PARTITION instead of the geometry:
+  // unknowns only ranks of the lower half touch go left, only ranks of the upper half right, the rest is the separator
+  // (valid: every matrix entry comes from one element, and an element belongs to one rank).  Subtree r of partition()
+  // is then exactly the interior of rank r's row block: every matrix entry of its columns is complete on rank r without
+  // any communication, and only entries among separator ("top") unknowns have to be summed over the ranks
+  // (rank_aligned()).
+  void analyze(const Csr& pattern, const double* coords, int dim, int leaf_size = 64, const unsigned long long* rank_mask = nullptr,
+               int world = 1);
   // vals aligned with pattern.colidx of analyze(); returns false on a non-positive pivot.
   bool factor(const double* vals);
   // in-place solve; b has N entries in the ORIGINAL ordering.
@@ -43,7 +51,14 @@ class MfChol {
   // (sum over ranks, in place, of `count` doubles -- the only collective), every rank factors the top and finishes its
   // own unknowns, and a second allreduce assembles x.  Returns false on a non-positive pivot on ANY rank.
   typedef std::function<void(double*, long long)> Allreduce;
-  bool factor_solve_dist(const double* vals, double* b, const CholPartition& part, int rank, const Allreduce& allreduce);
+  // vals_local (needs rank_aligned(part.world)): vals holds only THIS rank's row-block contributions; the entries of the
+  // top nodes travel with the Schur complements in the first collective and are summed there.
+  bool factor_solve_dist(const double* vals, double* b, const CholPartition& part, int rank, const Allreduce& allreduce,
+                         bool vals_local = false);
+  // true if analyze() was given rank masks for this world and every guided split succeeded
+  bool rank_aligned(int world) const { return world > 1 && aligned_world_ == world; }
+  // indices into vals of the entries assembled into the replicated top nodes of `part`
+  std::vector<int> top_value_indices(const CholPartition& part) const;
   // subtree split for `world` ranks (power of two, complete binary top); world = 1 in the result means "not splittable"
   CholPartition partition(int world) const;
   int size() const { return n_; }
@@ -74,11 +89,13 @@ class MfChol {
     std::vector<std::vector<int>> own;
   };
   int build(std::vector<int>& dofs, int lo, int hi, const Csr& A, const double* coords, int dim, int leaf,
-            std::vector<int>& label, std::atomic<int>& next_label, Subtree& sub, int par_depth);
+            std::vector<int>& label, std::atomic<int>& next_label, Subtree& sub, int par_depth,
+            const unsigned long long* mask = nullptr, int rlo = 0, int rhi = 1);
   void factor_node(int t, const double* vals, bool& ok);
   void forward_node(int t, double* y) const;
   void backward_node(int t, double* y) const;
-  int n_ = 0, max_front_ = 0;
+  int n_ = 0, max_front_ = 0, aligned_world_ = 1, a_nnz_ = 0;
+  std::atomic<bool> align_failed_{false};
   double flops_ = 0;
   std::vector<int> perm_, iperm_;       // perm_[new] = old ; iperm_[old] = new
   std::vector<Node> nodes_;             // postorder: children before parents

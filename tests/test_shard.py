@@ -177,10 +177,39 @@ def test_sharded_solve_matches_unsharded_two_processes_one_gpu(gpu_required, kin
     assert np.array_equal(z0, z1) and np.array_equal(its0, its1)          # ranks stay in lock step, bit for bit
     assert st0["calls"] == st1["calls"] > 0
     # the factorisation itself is split over the two ranks (one nested-dissection subtree each, replicated top)
-    # (fem1d L=4 has 32 unknowns: one leaf front, nothing to split -- replicated there)
-    want = 2 if kind == "fem2d" else 1
-    assert st0["split_world"] == st1["split_world"] == want and (st0["exchange_doubles"] > 0) == (want == 2)
+    # (the top of the tree follows the row partition, so even fem1d L=4 with its 32 unknowns splits)
+    assert st0["split_world"] == st1["split_world"] == 2 and st0["exchange_doubles"] > 0
+    assert st0["values_local"] and st1["values_local"]
     assert np.linalg.norm(z0 - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_hessian_values_stay_on_their_rank(gpu_required, world):
+    """Reduce-to-owner (row (e)): the factorisation's subtrees follow the row partition, so the all-nnz allreduce of the
+    Hessian values per Newton step is gone -- only entries among separator unknowns travel, inside the Schur-complement
+    collective.  Same z as the unsharded solve; against MGB_RANK_ALIGNED=0 (geometric tree + full allreduce, the previous
+    scheme) one collective and 40-60 % of the bytes per Newton step disappear."""
+    import mgb_amd as M
+    kind, L, p = "fem2d", 5, 1.5
+    ref = M.mpi_to_native(M.fem2d_mpi_solve(L=L, p=p)).z
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["MGB_RANK_ALIGNED"] = mode
+        try:
+            out = _run(_gpu_worker, world, (kind, L, p))
+        finally:
+            del os.environ["MGB_RANK_ALIGNED"]
+        zs, its, sts = [o[1] for o in out], [o[2] for o in out], [o[3] for o in out]
+        assert all(np.array_equal(z, zs[0]) for z in zs) and all(np.array_equal(i, its[0]) for i in its)
+        assert np.linalg.norm(zs[0] - ref) <= 1e-10 * np.linalg.norm(ref)
+        assert all(st["split_world"] == world and st["values_local"] == (mode == "1") for st in sts)
+        steps = int(its[0].sum())
+        res[mode] = (sts[0]["calls"] / steps, sts[0]["bytes"] / steps)
+    print("world %d: collectives / bytes per Newton step: aligned %.1f / %.0f, allreduce of all values %.1f / %.0f" % (
+        world, *res["1"], *res["0"]))
+    assert res["1"][0] < res["0"][0] - 0.5        # one collective per factorisation less (trial counts differ a little)
+    assert res["1"][1] < 0.7 * res["0"][1]        # L=5: 41-60 % fewer bytes; at L=7 x 8 ranks 6.5 -> 2.9 MB per step (DESIGN section 6)
 
 
 def _nccl_worker(rank, world, port, q):
@@ -279,6 +308,27 @@ def _chol_dist_worker(rank, world, port, q):
             bad[diag[0]] = -1.0
             rc = _lib.load().mgb_hostchol_factor_solve_dist(ch, rank, world, cb, None, dptr(bad), dptr(f64(g)), dptr(x.copy()))
             out[kind]["bad_rc"] = rc
+            # reduce-to-owner: the tree's top follows the row partition, every rank passes only ITS row block's contributions
+            # to the matrix entries; the entries among separator unknowns ride in the first collective
+            chr_ = C.c_void_p()
+            call("mgb_plan_hostchol_create_ranked", p, dim, K, world, block, C.byref(chr_))
+            al, ntop = C.c_int(), C.c_int()
+            call("mgb_hostchol_rank_aligned", chr_, world, C.byref(al), C.byref(ntop))
+            ps = C.c_void_p()
+            r0, r1 = C.c_int(), C.c_int()
+            call("mgb_plan_shard", p, S, K, rank, world, block, C.byref(ps), C.byref(r0), C.byref(r1))
+            a_loc = np.empty(nz)
+            call("mgb_plan_eval_host", ps, dptr(f64(Y[r0.value:r1.value].copy())), dptr(a_loc))
+            xl = np.empty(N)
+            n1 = len(calls)
+            call("mgb_hostchol_factor_solve_dist_local", chr_, rank, world, cb, None, dptr(a_loc), dptr(f64(g)), dptr(xl))
+            sw2 = C.c_int()
+            call("mgb_hostchol_partition", chr_, world, C.byref(sw2), 0, C.byref(nn), None)
+            out[kind].update(aligned=al.value, ntop=ntop.value, nz=nz, split_ranked=sw2.value, x_local=xl,
+                             err_local=float(np.abs(xl - x_ref).max() / np.abs(x_ref).max()), exchanges_local=calls[n1:],
+                             local_nonzero=int(np.count_nonzero(a_loc)))
+            call("mgb_plan_destroy", ps)
+            call("mgb_hostchol_destroy", chr_)
             call("mgb_hostchol_destroy", ch)
             call("mgb_plan_destroy", p)
             call("mgb_geo_destroy", h)
@@ -307,6 +357,14 @@ def test_distributed_factor_solve_host_gloo(world):
             assert np.array_equal(r["x"], rs[0]["x"])
             assert len(r["exchanges"]) == 2 and r["exchanges"] == rs[0]["exchanges"]
             assert r["bad_rc"] == -3                                   # MGB_E_NUMERIC everywhere
+            # reduce-to-owner (tree top = row partition): same solution from rank-local matrix entries, still two collectives,
+            # and the only matrix entries that travel are the ones among separator unknowns -- a small fraction of nnz
+            assert r["aligned"] == 1 and r["split_ranked"] == world
+            assert r["err_local"] < 1e-11
+            assert np.array_equal(r["x_local"], rs[0]["x_local"])
+            assert len(r["exchanges_local"]) == 2 and r["exchanges_local"] == rs[0]["exchanges_local"]
+            assert 0 < r["ntop"] < (0.2 if kind == "fem2d" else 0.05) * r["nz"]
+            assert r["local_nonzero"] < r["nz"]                          # a rank's shard really does not see every entry
 
 
 def test_partition_falls_back_to_replication(lib):
