@@ -184,6 +184,30 @@ __device__ __forceinline__ void factor_diag_block(const double* D, int kw, doubl
   }
 }
 
+// The wave-0 part of factor_diag_block without its barriers (front_step2: the other three waves work on their panel
+// blocks meanwhile): D (LDS, row stride LP) -> Lo[i * LP + j], reciprocal diagonal, zeros above it.  Threads 0..63 only.
+__device__ __forceinline__ void factor_block_wave0(const double* D, int kw, double* Lo, int* fail) {
+  const int tid = threadIdx.x, i = tid & 31, h = tid >> 5;
+  double a[PB / 2];
+#pragma unroll
+  for (int q = 0; q < PB / 2; ++q) {
+    const int j = 4 * (q >> 1) + 2 * h + (q & 1);
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < kw && j < kw && j <= i) v = D[i * LP + j];
+    a[q] = v;
+  }
+  bool bad = false;
+  factor_rounds<false>(a, (lds_f64)Lo, i, h, bad, PB);
+  if (bad && tid == 0) atomicOr(fail, 1);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < PB / 2; ++q) {
+    const int j = 4 * (q >> 1) + 2 * h + (q & 1);
+    Lo[i * LP + j] = (j <= i) ? a[q] : 0.0;
+  }
+}
+
 // Start of a height: workgroup = 32 columns x 256 rows of one front, in gather form.  (1) every lower entry (and the
 // right-hand-side row nf) of the columns is WRITTEN as child0 + child1 contribution (or 0), found through the
 // per-child inverse index maps (parent row -> child boundary row, -1 if absent): no read-modify-write chains,
@@ -504,6 +528,223 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       if (i <= nf && j < nf && i >= j && !(i < kc && j < kc)) F[(long long)ld * j + i] = acc[bj][reg];
     }
   STAMP(3);
+  STAMP(7);
+}
+
+// TWO panels per launch (columns k0..k0+63 of every front of the height that still has them): halves the launches of the
+// multi-panel heights and the passes over the trailing matrix (what bounds the large 3-D fronts: a rank-64 instead of two
+// rank-32 updates per C tile).  The first pivot block L11 comes from the previous launch as before.  The second one cannot
+// (it needs the first panel's update), so EVERY workgroup re-derives it: L21 = A21 L11^-T (32 rows), A22 - L21 L21' on the
+// matrix cores, factor -- pivot_path's work, 5 us of redundant flops instead of a launch boundary, as front_single does --
+// and while wave 0 factors, waves 1..3 already solve the tile's panel blocks against L11 and subtract X1 L21' from their
+// second halves.  Then X2 = (.) L22^-T, the mirrored rows of L, and one rank-64 update of the C tile.  Tile (0,0) of every
+// front publishes L21 and the second pivot block; the pivot workgroups (first npiv) do the same for rows k2..k2+31 only
+// and factor the corner that becomes the pivot block of the NEXT launch.
+// LDS (dynamic, 115 KB): L11 and L22 in quad order, L21, the corner, the factor scratch, two 64 x 64 panel blocks.
+constexpr int kStep2Lds = (2 * PB * PB + 3 * PB * LP + 2 * 2 * PB * (TS + 8)) * (int)sizeof(double);
+
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void front_step2_kernel(
+    const StepTile* __restrict__ tiles, int p, int npiv, double* fronts, const double* __restrict__ linv_ro, double* linv, int* fail,
+    long long* prof) {
+  constexpr int TP = TS + 8;
+  extern __shared__ __attribute__((aligned(32))) double sh2[];
+  double* Lc1 = sh2;                    // L11, quad order
+  double* Lc2 = Lc1 + PB * PB;          // L22, quad order
+  double* P = Lc2 + PB * PB;            // L21: P[r * LP + m]
+  double* D = P + PB * LP;              // corner A22 - L21 L21' (pivot workgroups: later the next launch's pivot block)
+  double* Lo = D + PB * LP;             // factor scratch / L22 row-major
+  double* ATI = Lo + PB * LP;           // AT[q * TP + r]: q < 32 first panel, q >= 32 second panel
+  double* ATJ = ATI + 2 * PB * TP;
+  STAMP(0);
+  const StepTile t = tiles[blockIdx.x];
+  const bool is_piv = (int)blockIdx.x < npiv;      // workgroup-uniform
+  const int nf = t.nf, ld = nf + 1, k0 = p * PB, k1 = min(t.ns, k0 + PB), k2 = min(t.ns, k1 + PB), kw = k1 - k0, kw2 = k2 - k1;
+  const int kw3 = min(PB, t.ns - k2);              // pivot workgroups: width of the next pivot block
+  double* F = fronts + t.off;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
+  const int r0 = is_piv ? k2 : k2 + TS * t.ti, c0 = is_piv ? k2 : k2 + TS * t.tj;
+  const bool diag = is_piv || (t.ti == t.tj);
+  const int rows_here = is_piv ? kw3 : TS;         // pivot workgroups stage only the rows of the next pivot block
+  typedef double v4f64 __attribute__((ext_vector_type(4)));
+  for (int idx = tid; idx < PB * PB; idx += TB) Lc1[lq_index(idx % PB, idx / PB)] = linv_ro[t.loff + PB * PB + idx];
+  // second pivot block: its 32 rows of the first panel (waves 0, 1: four lanes per row) and its lower triangle as three
+  // 16x16 blocks in the MFMA result layout (waves 0..2) -- see pivot_path
+  const int bi = (w + 1) >> 1, bj3 = w >> 1, ci = 16 * bi + li;
+  v4f64 accD = v4f64{0.0, 0.0, 0.0, 0.0};
+  if (w < 3) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int j = 16 * bj3 + lk + 4 * reg;
+      accD[reg] = (j <= ci && ci < kw2) ? F[(long long)ld * (k1 + j) + k1 + ci] : 0.0;
+    }
+  }
+  const int pr = 16 * w + (lane >> 2), c4 = lane & 3;
+  double f[PB / 4];
+  if (w < 2) {
+#pragma unroll
+    for (int k = 0; k < PB / 4; ++k) {
+      const int m = c4 + 4 * k;
+      f[k] = (m < kw && pr < kw2) ? F[(long long)ld * (k0 + m) + k1 + pr] : 0.0;
+    }
+  }
+  // the two-panel blocks of the tile's rows (and columns off the diagonal): thread = one row, every fourth column; ALL loads
+  // are issued before the first LDS store (the store-as-you-go loop serialised into ~4 memory round trips, 7.4 us)
+  const int sr = tid & (TS - 1), sq0 = tid >> 6;
+  double vI[2 * PB / 4], vJ[2 * PB / 4];
+  {
+    const bool okI = sr < rows_here && r0 + sr <= nf, okJ = !diag && c0 + sr <= nf;
+#pragma unroll
+    for (int u = 0; u < 2 * PB / 4; ++u) {
+      const int q = sq0 + 4 * u;
+      const int col = (q < PB) ? k0 + q : k1 + q - PB;
+      const bool okc = (q < PB) ? (q < kw) : (q - PB < kw2);
+      const double* src = F + (long long)ld * (okc ? col : k0);      // clamped to a valid column when there is none
+      vI[u] = okI ? src[r0 + sr] : 0.0;
+      vJ[u] = okJ ? src[c0 + sr] : 0.0;
+      if (!okc) vI[u] = vJ[u] = 0.0;
+    }
+  }
+  // C tile (pivot workgroups: the corner of the next pivot block, on waves 0..2), requested now
+  const int kc = (!is_piv && t.ti == 0 && t.tj == 0) ? min(t.ns, k2 + PB) : 0;
+  const int i = r0 + 16 * w + li;
+  double c[4][4];
+  v4f64 accN = v4f64{0.0, 0.0, 0.0, 0.0};
+  if (is_piv) {
+    if (w < 3) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int j = 16 * bj3 + lk + 4 * reg;
+        accN[reg] = (j <= ci && ci < kw3) ? F[(long long)ld * (k2 + j) + k2 + ci] : 0.0;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int j = c0 + 16 * bj + lk + 4 * reg;
+        c[bj][reg] = (i <= nf && j < nf && i >= j && !(i < kc && j < kc)) ? F[(long long)ld * j + i] : 0.0;
+      }
+  }
+#pragma unroll
+  for (int u = 0; u < 2 * PB / 4; ++u) {
+    ATI[(sq0 + 4 * u) * TP + sr] = vI[u];
+    if (!diag) ATJ[(sq0 + 4 * u) * TP + sr] = vJ[u];
+  }
+  __syncthreads();
+  STAMP(1);
+  if (w < 2) {      // L21 = A21 L11^-T
+    trsm_quad(f, Lc1, c4);
+#pragma unroll
+    for (int k = 0; k < PB / 4; ++k) P[pr * LP + c4 + 4 * k] = f[k];
+  }
+  __syncthreads();
+  if (w < 3) {      // corner - L21 L21'
+    const double* PI = P + ci * LP + lk;
+    const double* PJ = P + (16 * bj3 + li) * LP + lk;
+#pragma unroll
+    for (int ks = 0; ks < PB / 4; ++ks) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(PJ[4 * ks], -PI[4 * ks], accD, 0, 0, 0);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) D[ci * LP + 16 * bj3 + lk + 4 * reg] = accD[reg];
+  }
+  __syncthreads();
+  STAMP(2);
+  if (w == 0) {
+    factor_block_wave0(D, kw2, Lo, fail);      // L22
+  } else {
+    // 16-row blocks of the panel blocks: X1 = A1 L11^-T in place, then A2 -= X1 L21' (both wave-local)
+    const int nblk = is_piv ? 2 : (diag ? 4 : 8);
+    for (int b = w - 1; b < nblk; b += 3) {
+      double* AT = (b < 4) ? ATI : ATJ;
+      const int rb = 16 * (b & 3), r = rb + (lane >> 2);
+      double g[PB / 4];
+#pragma unroll
+      for (int k = 0; k < PB / 4; ++k) g[k] = AT[(c4 + 4 * k) * TP + r];
+      trsm_quad(g, Lc1, c4);
+#pragma unroll
+      for (int k = 0; k < PB / 4; ++k) AT[(c4 + 4 * k) * TP + r] = g[k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      v4f64 a2[2];
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) a2[bj][reg] = AT[(PB + 16 * bj + lk + 4 * reg) * TP + rb + li];
+#pragma unroll
+      for (int ks = 0; ks < PB / 4; ++ks) {
+        const double bv = -AT[(4 * ks + lk) * TP + rb + li];
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+          a2[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(P[(16 * bj + li) * LP + 4 * ks + lk], bv, a2[bj], 0, 0, 0);
+      }
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) AT[(PB + 16 * bj + lk + 4 * reg) * TP + rb + li] = a2[bj][reg];
+    }
+  }
+  __syncthreads();
+  STAMP(3);
+  for (int idx = tid; idx < PB * PB; idx += TB) Lc2[lq_index(idx % PB, idx / PB)] = Lo[(idx % PB) * LP + idx / PB];
+  if (!is_piv && t.ti == 0 && t.tj == 0 && kw2 > 0) {      // this front's publisher of the second pivot block and of the rows of L21 (if it has a second panel)
+    double* lp = linv + t.loff + 2 * PB * PB;
+    for (int idx = tid; idx < PB * PB; idx += TB) {
+      const int r = idx / PB, m = idx % PB;
+      lp[idx] = Lo[r * LP + m];
+      lp[PB * PB + idx] = Lo[m * LP + r];
+      if (r < kw2 && m < kw) F[(long long)ld * (k1 + r) + k0 + m] = P[r * LP + m];
+    }
+  }
+  __syncthreads();
+  trsm_block64(ATI + PB * TP, TP, Lc2);      // X2 = (A2 - X1 L21') L22^-T
+  if (!diag) trsm_block64(ATJ + PB * TP, TP, Lc2);
+  __syncthreads();
+  STAMP(4);
+  if (is_piv) {
+    // next pivot block: corner - [X1 X2] [X1 X2]' over its 32 rows, then the factor the NEXT launch starts from
+    if (w < 3) {
+      const double* PI = ATI + ci + lk * TP;
+      const double* PJ = ATI + 16 * bj3 + li + lk * TP;
+#pragma unroll
+      for (int ks = 0; ks < 2 * PB / 4; ++ks) accN = __builtin_amdgcn_mfma_f64_16x16x4f64(PJ[4 * ks * TP], -PI[4 * ks * TP], accN, 0, 0, 0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) D[ci * LP + 16 * bj3 + lk + 4 * reg] = accN[reg];
+    }
+    __syncthreads();
+    STAMP(5);
+    factor_diag_block(D, kw3, Lo, linv + t.loff + 4 * PB * PB, fail, prof);
+    STAMP(7);
+    return;
+  }
+  if (t.tj == 0) {      // finished rows of L (both panels) go to the mirrored half
+    for (int idx = tid; idx < TS * 2 * PB; idx += TB) {
+      const int r = idx / (2 * PB), q = idx % (2 * PB);
+      const int col = (q < PB) ? k0 + q : k1 + q - PB;
+      const bool okc = (q < PB) ? (q < kw) : (q - PB < kw2);
+      if (r0 + r <= nf && okc) F[(long long)ld * (r0 + r) + col] = ATI[q * TP + r];
+    }
+  }
+  // rank-64 update of the C tile (layout and operand order of front_step)
+  const double* LI = ATI + 16 * w + li + lk * TP;
+  const double* LJ = (diag ? ATI : ATJ) + li + lk * TP;
+  v4f64 acc[4];
+#pragma unroll
+  for (int bj = 0; bj < 4; ++bj) acc[bj] = v4f64{c[bj][0], c[bj][1], c[bj][2], c[bj][3]};
+#pragma unroll
+  for (int ks = 0; ks < 2 * PB / 4; ++ks) {
+    const double bv = -LI[4 * ks * TP];
+#pragma unroll
+    for (int bj = 0; bj < 4; ++bj)
+      acc[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(LJ[4 * ks * TP + 16 * bj], bv, acc[bj], 0, 0, 0);
+  }
+#pragma unroll
+  for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int j = c0 + 16 * bj + lk + 4 * reg;
+      if (i <= nf && j < nf && i >= j && !(i < kc && j < kc)) F[(long long)ld * j + i] = acc[bj][reg];
+    }
   STAMP(7);
 }
 
@@ -1071,6 +1312,14 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
     const char* e = std::getenv("MGB_CHOL_SINGLE");
     return !(e && e[0] == '0');
   }();
+  static const bool step2_ok = [] {      // MGB_CHOL_STEP2=0: one panel per launch everywhere (the scheme before front_step2)
+    const char* e = std::getenv("MGB_CHOL_STEP2");
+    return !(e && e[0] == '0');
+  }();
+  static const int step2_max_tiles = [] {
+    const char* e = std::getenv("MGB_CHOL_STEP2_TILES");
+    return e ? std::atoi(e) : 224;
+  }();
   static const int split_nf = [] {
     const char* e = std::getenv("MGB_BWD_SPLIT_NF");
     return e ? std::atoi(e) : 192;
@@ -1136,11 +1385,23 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
       Range rt{(int)tiles.size(), 0};
       double bytes = 0;
       int npiv = 0;
+      // two panels per launch (front_step2) while the height has at least two left; the odd last one runs front_step
+      // ... and only where the launch is latency-bound (its tiles fit the chip in one round): front_step2 holds 115 KB of
+      // LDS, one workgroup per CU, and loses against two rank-32 launches at 2-3 workgroups per CU on the big 3-D heights
+      int ntile2 = 0;
+      for (int t : mine) {
+        const GNode& g = nodes[t];
+        if (g.ns <= p * PB) continue;
+        const int k2 = std::min(g.ns, (p + 2) * PB), Tr = (g.nf + 1 - k2 + TS - 1) / TS, Tc = std::max(1, (g.nf - k2 + TS - 1) / TS);
+        for (int ti = 0; ti < Tr; ++ti) ntile2 += std::min(ti, Tc - 1) + 1;
+      }
+      const bool pair = step2_ok && !hp.single && p + 1 < npanel && ntile2 <= step2_max_tiles;
+      const int np = pair ? 2 : 1;
       for (int pass = 0; pass < 2; ++pass)
         for (int t : mine) {
           const GNode& g = nodes[t];
           if (g.ns <= p * PB) continue;
-          const int k1 = std::min(g.ns, (p + 1) * PB), kw = k1 - p * PB;
+          const int k1 = std::min(g.ns, (p + np) * PB), kw = k1 - p * PB;      // first trailing row, pivots of this launch
           StepTile st{};
           st.off = g.off;
           st.loff = g.loff + (long long)p * 2 * PB * PB;
@@ -1197,7 +1458,10 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
       rt.cnt = (int)tiles.size() - rt.ofs;
       hp.step.push_back(rt);
       hp.step_bytes.push_back(bytes);
+      hp.step_p.push_back(p);
+      hp.step_pair.push_back(pair ? 1 : 0);
       launches_++;
+      if (pair) ++p;
     }
     // backward
     hp.split = hp.max_nf > split_nf;
@@ -1292,6 +1556,7 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
   ck(hipFuncSetAttribute((const void*)backward_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
   ck(hipFuncSetAttribute((const void*)backward_rect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
   ck(hipFuncSetAttribute((const void*)front_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024), "attr");
+  ck(hipFuncSetAttribute((const void*)front_step2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kStep2Lds), "attr");
 }
 
 // The whole chain is launch-bound (83 dependent launches at fem2d L=7), so it is captured once per
@@ -1362,10 +1627,14 @@ void GpuChol::enqueue_forward(hipStream_t st, const std::vector<HeightPlan>& pla
                        d_asm_src_, d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_fronts_, d_linv_, d_fail_,
                        d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr);
     if (tm) tm->end(st);
-    for (size_t p = 0; p < hp.step.size(); ++p) {
-      if (tm) tm->begin(st, KC_CHOL_STEP, hp.step_bytes[p]);
-      hipLaunchKernelGGL(front_step_kernel, dim3(hp.step[p].cnt), dim3(TB), 0, st, d_tiles_ + hp.step[p].ofs, (int)p,
-                         hp.step_npiv[p], d_fronts_, d_linv_, d_linv_, d_fail_, d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr);
+    for (size_t q = 0; q < hp.step.size(); ++q) {
+      if (tm) tm->begin(st, KC_CHOL_STEP, hp.step_bytes[q]);
+      if (hp.step_pair[q])
+        hipLaunchKernelGGL(front_step2_kernel, dim3(hp.step[q].cnt), dim3(TB), kStep2Lds, st, d_tiles_ + hp.step[q].ofs, hp.step_p[q],
+                           hp.step_npiv[q], d_fronts_, d_linv_, d_linv_, d_fail_, d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr);
+      else
+        hipLaunchKernelGGL(front_step_kernel, dim3(hp.step[q].cnt), dim3(TB), 0, st, d_tiles_ + hp.step[q].ofs, hp.step_p[q],
+                           hp.step_npiv[q], d_fronts_, d_linv_, d_linv_, d_fail_, d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr);
       if (tm) tm->end(st);
     }
   }

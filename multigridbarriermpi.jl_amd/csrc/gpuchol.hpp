@@ -171,6 +171,8 @@ class GpuChol {
     std::vector<Range> step;
     Range single_tiles{0, 0};
     std::vector<int> step_npiv;   // leading pivot workgroups of every step launch
+    std::vector<int> step_p;      // first panel of the launch
+    std::vector<char> step_pair;  // 1: two panels (front_step2)
     std::vector<double> step_bytes;
     double start_bytes, rect_bytes, tri_bytes;
     int max_nf;
