@@ -7,7 +7,7 @@ import json
 import sys
 
 CLASSES = {          # rocprofv3 kernel name fragment -> bench.py kernel class
-    "front_start_kernel": "chol_front_start", "front_step_kernel": "chol_front_step", "front_single_kernel": "chol_front_single", "front_leaf_kernel": "chol_front_leaf",
+    "front_start_kernel": "chol_front_start", "front_step_kernel": "chol_front_step", "front_step2_kernel": "chol_front_step", "front_single_kernel": "chol_front_single", "front_leaf_kernel": "chol_front_leaf",
     "backward_rect_kernel": "chol_backward_rect", "backward_kernel": "chol_backward",
     "spmv_kernel<4>": "apply_D", "spmv_kernel<8>": "hessian_assemble", "spmv_kernel<16>": "restrict",
     "barrier_f0_kernel": "barrier_f0_unfused", "trial_f0_kernel": "barrier_f0", "barrier_f1_kernel": "barrier_f1", "barrier_f2_kernel": "barrier_f2",
