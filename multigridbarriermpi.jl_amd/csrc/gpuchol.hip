@@ -448,7 +448,7 @@ __device__ inline void pivot_path(const StepTile& t, int p, double* sh, double* 
 }
 
 
-__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 2))) void front_step_kernel(const StepTile* __restrict__ tiles, int p, int npiv, double* fronts,
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 3))) void front_step_kernel(const StepTile* __restrict__ tiles, int p, int npiv, double* fronts,
                                                          const double* __restrict__ linv_ro, double* linv, int* fail,
                                                          long long* prof) {
   // panel rows of the tile, transposed: AT[q * TP + r] = (row r, panel column q): unit stride over the rows for the
