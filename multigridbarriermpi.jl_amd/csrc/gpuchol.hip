@@ -219,7 +219,7 @@ __global__ __launch_bounds__(TB, 3) void front_start_kernel(const GNode* __restr
                                                           const int* __restrict__ asm_pos, const double* __restrict__ vals,
                                                           const int* __restrict__ perm, const double* __restrict__ b,
                                                           const double* __restrict__ fronts_ro, double* fronts, double* linv,
-                                                          int* fail, long long* prof) {
+                                                          int* fail, long long* prof, int dedicated_pivot) {
   __shared__ double sh[2 * PB * LP];
   __shared__ int cb[2][PB];
   STAMP(0);
@@ -235,6 +235,62 @@ __global__ __launch_bounds__(TB, 3) void front_start_kernel(const GNode* __restr
   const bool has[2] = {job.cld[0] > 0, job.cld[1] > 0};
   const int* __restrict__ inv0 = pinv + (has[0] ? job.iofs : 0);
   const int* __restrict__ inv1 = pinv + (has[1] ? job.iofs + ld : 0);
+  if (job.rb < 0) {
+    // Dedicated pivot job (one per front, first in the launch): the first pivot block is gathered straight into LDS --
+    // child0 + child1, then the matrix entries, the order of the assembling workgroups -- and factored at once, instead
+    // of waiting for the assembly of 256 x 32 entries, its read-modify-write of the matrix entries in global memory and
+    // the reload of the block (two round trips on what the first panel launch waits for).  Bitwise the same block.
+    const int kw = min(PB, ns);
+    double* D = sh;
+    int apos[2], asrc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = job.a0 + u * TB + tid;
+      apos[u] = (k < job.a1) ? asm_pos[k] : -1;
+      asrc[u] = (k < job.a1) ? asm_src[k] : 0;
+    }
+    if (tid < 2 * PB) {
+      const int s = tid / PB, c = tid % PB;
+      cb[s][c] = (has[s] && c < kw) ? (s ? inv1 : inv0)[c] : -1;
+    }
+    double aval[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) aval[u] = vals[asrc[u]];
+    __syncthreads();
+    STAMP(1);
+    const double* __restrict__ B0 = fronts_ro + boff[0];
+    const double* __restrict__ B1 = fronts_ro + boff[1];
+    {
+      const int i = tid % PB, jg = tid / PB;      // 32 rows x 8 groups of 4 columns
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = jg * 4 + u;
+        const int a0 = cb[0][i], q0 = cb[0][j], a1 = cb[1][i], q1 = cb[1][j];
+        const bool in = (j <= i && i < kw), ok0 = in && a0 >= 0 && q0 >= 0, ok1 = in && a1 >= 0 && q1 >= 0;
+        const double x0 = B0[ok0 ? (long long)cld[0] * q0 + a0 : 0];
+        const double x1 = B1[ok1 ? (long long)cld[1] * q1 + a1 : 0];
+        v[u] = (ok0 ? x0 : 0.0) + (ok1 ? x1 : 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) D[i * LP + jg * 4 + u] = v[u];
+    }
+    __syncthreads();
+    STAMP(2);
+    auto add_entry = [&](int pos, double v) {
+      if (pos < 0) return;
+      const int col = pos / ld, row = pos - col * ld;
+      if (row < PB && col < PB) D[row * LP + col] += v;
+    };
+#pragma unroll
+    for (int u = 0; u < 2; ++u) add_entry(apos[u], aval[u]);
+    for (int k = job.a0 + 2 * TB + tid; k < job.a1; k += TB) add_entry(asm_pos[k], vals[asm_src[k]]);
+    __syncthreads();
+    STAMP(5);
+    factor_diag_block(D, kw, sh + PB * LP, linv + job.loff, fail, prof);
+    STAMP(7);
+    return;
+  }
   const int i = c0 + job.rb * TB + tid;        // one row per thread: the workgroup owns rows [c0 + 256 rb, +256)
   // everything that only needs the descriptor is requested together: the column maps, this thread's row maps, the first
   // assembly indices and the right-hand-side permutation (the chain is descriptor -> indices -> data)
@@ -280,7 +336,7 @@ __global__ __launch_bounds__(TB, 3) void front_start_kernel(const GNode* __restr
   if (apos0 >= 0) F[apos0] += aval0;      // first batch from registers, the rest (large fronts) the long way
   for (int k = job.a0 + TB + tid; k < job.a1; k += TB) F[asm_pos[k]] += vals[asm_src[k]];
   if (prm >= 0) F[(long long)ld * crhs + nf] += bval;      // min(c1, ns) - c0 <= 32 <= TB columns: one per thread
-  if (job.chunk == 0 && job.rb == 0 && ns > 0) {
+  if (job.chunk == 0 && job.rb == 0 && ns > 0 && !dedicated_pivot) {      // (the schedule without pivot jobs)
     __syncthreads();
     STAMP(3);
     const int kw = min(PB, ns);
@@ -1316,6 +1372,11 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
     const char* e = std::getenv("MGB_CHOL_STEP2");
     return !(e && e[0] == '0');
   }();
+  static const bool start_pivot_ok = [] {      // MGB_CHOL_START_PIVOT=0: the first pivot block is factored by the assembling workgroup
+    const char* e = std::getenv("MGB_CHOL_START_PIVOT");
+    return !(e && e[0] == '0');
+  }();
+  start_pivot_ = start_pivot_ok;
   static const int step2_max_tiles = [] {
     const char* e = std::getenv("MGB_CHOL_STEP2_TILES");
     return e ? std::atoi(e) : 224;
@@ -1375,7 +1436,16 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
         const double cnb = nodes[c].nf - nodes[c].ns;
         hp.start_bytes += 0.5 * cnb * cnb * 8.0;     // child entry read (the parent entry write is counted above)
       }
-      if (!hp.single && !hp.leaf) starts.insert(starts.end(), sjobs[t].begin(), sjobs[t].end());
+    }
+    if (!hp.single && !hp.leaf) {
+      if (start_pivot_ok)      // dedicated pivot jobs first: they are what the first panel launch waits for
+        for (int t : mine)
+          if (nodes[t].ns > 0 && !sjobs[t].empty()) {
+            StartJob pj = sjobs[t].front();      // chunk 0, row block 0: its assembly range covers the pivot block
+            pj.rb = -1;
+            starts.push_back(pj);
+          }
+      for (int t : mine) starts.insert(starts.end(), sjobs[t].begin(), sjobs[t].end());
     }
     hp.start.cnt = (int)starts.size() - hp.start.ofs;
     launches_++;
@@ -1625,7 +1695,7 @@ void GpuChol::enqueue_forward(hipStream_t st, const std::vector<HeightPlan>& pla
     if (tm) tm->begin(st, KC_CHOL_START, hp.start_bytes);
     hipLaunchKernelGGL(front_start_kernel, dim3(hp.start.cnt), dim3(TB), 0, st, d_nodes_, d_start_ + hp.start.ofs, d_pinv_,
                        d_asm_src_, d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_fronts_, d_linv_, d_fail_,
-                       d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr);
+                       d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr, start_pivot_ ? 1 : 0);
     if (tm) tm->end(st);
     for (size_t q = 0; q < hp.step.size(); ++q) {
       if (tm) tm->begin(st, KC_CHOL_STEP, hp.step_bytes[q]);

@@ -130,6 +130,7 @@ class GpuChol {
   int nroots_ = 0, max_root_nb_ = 0;
   double* d_xchg_ = nullptr;      // Schur exchange buffer (+ ntop_vals_ matrix entries of the top nodes behind it)
   bool vals_local_ = false;
+  bool start_pivot_ = true;       // front_start launches carry a dedicated pivot job per front
   int ntop_vals_ = 0;
   int* d_top_idx_ = nullptr;      // indices into d_vals of the entries assembled into the top nodes
   double* d_xsol_ = nullptr;      // n + 1: masked solution + pivot flag
