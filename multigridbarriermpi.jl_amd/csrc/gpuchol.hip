@@ -986,7 +986,8 @@ __global__ __launch_bounds__(TB, 4) void front_leaf_kernel(
     const double* __restrict__ b, double* fronts, double* linv, int* fail, long long* prof) {
   extern __shared__ __attribute__((aligned(32))) double sm[];
   STAMP(0);
-  const GNode nd = nodes[list[blockIdx.x]];
+  const GNode nd = nodes[blockIdx.x];      // per-launch copy in launch order: one descriptor round trip, not two
+  (void)list;
   const int nf = nd.nf, ld = nf + 1, ns = nd.ns, tid = threadIdx.x;
   constexpr int TP = TS + 8;      // row stride of the staged panel rows (as in front_step)
   __shared__ __attribute__((aligned(32))) double fixed[TP * PB + PB * (PB + 1) / 2];      // AT (also D) | Lo (packed)
@@ -1094,7 +1095,7 @@ __global__ __launch_bounds__(RT) void backward_rect_kernel(const GNode* __restri
                                                             double* rect) {
   extern __shared__ double sh[];      // xb[nb] | red[RT]
   const RectJob job = jobs[blockIdx.x];
-  const GNode nd = nodes[job.node];
+  const GNode nd = nodes[blockIdx.x];      // per-job copy of the node (no second descriptor round trip)
   const int nf = nd.nf, ns = nd.ns, nb = nf - ns;
   const int* bd = bdry_all + nd.bofs;
   double* xb = sh;
@@ -1114,7 +1115,8 @@ __global__ __launch_bounds__(NT) void backward_kernel(const GNode* __restrict__ 
                                                        const double* __restrict__ linv, const int* __restrict__ perm,
                                                        const double* __restrict__ rect, int use_rect, double* y, double* x) {
   extern __shared__ double sh[];      // u[ns] | xb[nb] | red[NT]
-  const GNode nd = nodes[list[blockIdx.x]];
+  const GNode nd = nodes[blockIdx.x];      // per-launch copy in launch order: one descriptor round trip, not two
+  (void)list;
   const int nf = nd.nf, ns = nd.ns, nb = nf - ns, ld = nf + 1, tid = threadIdx.x;
   const double* F = fronts + nd.off;
   double* u = sh;
@@ -1560,6 +1562,13 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
   d_asm_src_ = upload(asrc);
   d_asm_pos_ = upload(apos);
   d_lists_ = upload(lists);
+  {      // node descriptors in launch order (front_leaf, backward) and per backward_rect job
+    std::vector<GNode> hn(lists.size()), rn(rects.size());
+    for (size_t k = 0; k < lists.size(); ++k) hn[k] = nodes[lists[k]];
+    for (size_t k = 0; k < rects.size(); ++k) rn[k] = nodes[rects[k].node];
+    d_hnodes_ = upload(hn);
+    d_rnodes_ = upload(rn);
+  }
   d_start_ = upload(starts);
   d_tiles_ = upload(tiles);
   d_singles_ = upload(singles);
@@ -1678,7 +1687,7 @@ void GpuChol::enqueue_forward(hipStream_t st, const std::vector<HeightPlan>& pla
     if (hp.leaf) {
       if (tm) tm->begin(st, KC_CHOL_SINGLE, hp.start_bytes);
       const size_t lds = ((size_t)(hp.max_nf + 1) * hp.max_nf - (size_t)hp.max_nf * (hp.max_nf - 1) / 2) * sizeof(double);
-      hipLaunchKernelGGL(front_leaf_kernel, dim3(hp.nodes.cnt), dim3(TB), lds, st, d_nodes_, d_lists_ + hp.nodes.ofs, d_asm_src_,
+      hipLaunchKernelGGL(front_leaf_kernel, dim3(hp.nodes.cnt), dim3(TB), lds, st, d_hnodes_ + hp.nodes.ofs, d_lists_ + hp.nodes.ofs, d_asm_src_,
                          d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_linv_, d_fail_,
                          d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr);
       if (tm) tm->end(st);
@@ -1717,17 +1726,17 @@ void GpuChol::enqueue_backward(hipStream_t st, const std::vector<HeightPlan>& pl
     if (use_rect) {
       if (tm) tm->begin(st, KC_CHOL_BWD_RECT, hp.rect_bytes);
       hipLaunchKernelGGL(backward_rect_kernel, dim3(hp.rect.cnt), dim3(RT), (size_t)(hp.max_nf + RT) * sizeof(double), st,
-                         d_nodes_, d_rectjobs_ + hp.rect.ofs, d_bdry_, d_fronts_, d_y_, d_rect_);
+                         d_rnodes_ + hp.rect.ofs, d_rectjobs_ + hp.rect.ofs, d_bdry_, d_fronts_, d_y_, d_rect_);
       if (tm) tm->end(st);
     }
     if (tm) tm->begin(st, KC_CHOL_BWD, hp.tri_bytes + (use_rect ? 0.0 : hp.rect_bytes));
     if (hp.max_nf > 384)
       hipLaunchKernelGGL(backward_kernel<1024>, dim3(hp.nodes.cnt), dim3(1024), (size_t)(hp.max_nf + 1024 + PB) * sizeof(double),
-                         st, d_nodes_, d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_linv_, d_perm_, d_rect_, use_rect, d_y_,
+                         st, d_hnodes_ + hp.nodes.ofs, d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_linv_, d_perm_, d_rect_, use_rect, d_y_,
                          d_x);
     else
       hipLaunchKernelGGL(backward_kernel<256>, dim3(hp.nodes.cnt), dim3(256), (size_t)(hp.max_nf + 256 + PB) * sizeof(double),
-                         st, d_nodes_, d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_linv_, d_perm_, d_rect_, use_rect, d_y_,
+                         st, d_hnodes_ + hp.nodes.ofs, d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_linv_, d_perm_, d_rect_, use_rect, d_y_,
                          d_x);
     if (tm) tm->end(st);
   }

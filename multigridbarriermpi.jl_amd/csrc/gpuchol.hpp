@@ -159,6 +159,8 @@ class GpuChol {
   int* d_asm_src_ = nullptr;
   int* d_asm_pos_ = nullptr;
   int* d_lists_ = nullptr;        // node lists per height
+  GNode* d_hnodes_ = nullptr;     // ... and the node descriptors themselves in that order (leaf / backward launches)
+  GNode* d_rnodes_ = nullptr;     // node descriptor per backward_rect job
   StartJob* d_start_ = nullptr;
   StepTile* d_tiles_ = nullptr;
   SingleTile* d_singles_ = nullptr;
