@@ -271,7 +271,7 @@ def _chol_dist_worker(rank, world, port, q):
 
         cb = _lib.ALLREDUCE_FN(thunk)
         out = {}
-        for kind, L in (("fem2d", 4), ("fem1d", 7)):
+        for kind, L in ((("fem2d", 4), ("fem1d", 7)) if world < 8 else (("fem2d", 5), ("fem1d", 10))):      # 8 subtrees need a deeper tree
             h, p, n, S, K, block, N, nz = _full_plan(kind, L, L - 1)
             dim = 1 if kind == "fem1d" else 2
             nY = (dim + 1) * (dim + 2) // 2
@@ -338,7 +338,7 @@ def _chol_dist_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])      # 8 = BASELINE configs[2] (8x row-partitioned): three levels of guided splits
 def test_distributed_factor_solve_host_gloo(world):
     """The factorisation split by nested-dissection subtrees (one subtree per rank, replicated top, Schur complements and
     right-hand-side updates of the subtree roots summed over the ranks -- the scheme csrc/gpuchol.hip runs on the GPUs)
