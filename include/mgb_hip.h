@@ -149,6 +149,18 @@ int mgb_amg_level_size(mgb_amg a, int level, int* N, int* nnz_lower);
 /* device factorisation of `level` (built now if needed): *split_world = ranks it is split over by nested-dissection subtrees
  * on a sharded context (1 = replicated: single GPU, or a world the tree cannot be split into), doubles exchanged per Newton
  * system (subtree-root Schur complements + the assembled solution), kernel launches per Newton system */
+/* Float32 evaluation of f0 / f1 / f2 at a level (the reference runs Float32 on its Metal backend, test/test_utils.jl:67-88;
+ * SURVEY.md section 8 f3): the SpMV and barrier kernels instantiated for float -- float operators, weights, costs and vectors
+ * are shadows of the double ones, built on first use -- with s in / g, lower_vals out as float; f0 is summed in double from
+ * per-row float terms.  Single-GPU contexts.  There is no Float32 factorisation (fp64 runs at the fp32 vector rate on MI355X
+ * and the direct solve is latency-bound): mgb_amg_solve stays in double.  *_template_f64: the double instantiation of the
+ * same kernel templates, which must reproduce mgb_amg_f1 / f2 bit for bit (that is how the tests tie the float kernels to
+ * the production ones). */
+int mgb_amg_f0_f32(mgb_amg a, int level, const float* s, float t, double* f0);
+int mgb_amg_f1_f32(mgb_amg a, int level, const float* s, float t, float* g);
+int mgb_amg_f2_f32(mgb_amg a, int level, const float* s, float t, float* lower_vals);
+int mgb_amg_f1_template_f64(mgb_amg a, int level, const double* s, double t, double* g);
+int mgb_amg_f2_template_f64(mgb_amg a, int level, const double* s, double t, double* lower_vals);
 int mgb_amg_chol_info(mgb_amg a, int level, int* split_world, double* exchange_doubles, int* launches);
 /* *yes = 1 if the subtrees of the split follow the row partition: a rank's Hessian values are then used where they were
  * computed, only the entries among separator unknowns are summed (inside the Schur-complement collective, counted in

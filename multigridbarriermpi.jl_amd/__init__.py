@@ -892,6 +892,38 @@ class AMG:
         Lo = sp.csr_matrix((vals, ci, rp), shape=(N, N))
         return Lo + sp.tril(Lo, -1).T, vals
 
+    # Float32 evaluation (csrc/kernels_f32.hip): the same SpMV / barrier kernels instantiated for float
+    def f0_f32(self, l, s, t):
+        s = np.ascontiguousarray(s, dtype=np.float32)
+        y = C.c_double()
+        call("mgb_amg_f0_f32", self.handle, l, s.ctypes.data_as(_lib.c_flt_p), float(t), C.byref(y))
+        return y.value
+
+    def f1_f32(self, l, s, t):
+        s = np.ascontiguousarray(s, dtype=np.float32)
+        g = np.empty(self.level_size(l)[0], dtype=np.float32)
+        call("mgb_amg_f1_f32", self.handle, l, s.ctypes.data_as(_lib.c_flt_p), float(t), g.ctypes.data_as(_lib.c_flt_p))
+        return g
+
+    def f2_f32(self, l, s, t):
+        """Lower-triangle values of R'HR in the order of hessian_pattern(l), float32."""
+        s = np.ascontiguousarray(s, dtype=np.float32)
+        vals = np.empty(self.level_size(l)[1], dtype=np.float32)
+        call("mgb_amg_f2_f32", self.handle, l, s.ctypes.data_as(_lib.c_flt_p), float(t), vals.ctypes.data_as(_lib.c_flt_p))
+        return vals
+
+    def f1_template_f64(self, l, s, t):
+        s = f64(s)
+        g = np.empty(self.level_size(l)[0])
+        call("mgb_amg_f1_template_f64", self.handle, l, dptr(s), float(t), dptr(g))
+        return g
+
+    def f2_template_f64(self, l, s, t):
+        s = f64(s)
+        vals = np.empty(self.level_size(l)[1])
+        call("mgb_amg_f2_template_f64", self.handle, l, dptr(s), float(t), dptr(vals))
+        return vals
+
     def f2_hpc(self, l, s, t) -> HPCSparseMatrix:
         """The Newton matrix R'HR of level l as an HPCSparseMatrix (what `f2` returns in the reference and what
         test/test_newton_matrix_compare.jl:33-51 captures); `.local_block(rank, world)` gives the per-rank fields."""

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmgb_hip.so")
 c_int_p = C.POINTER(C.c_int)
 c_i32_p = C.POINTER(C.c_int32)
 c_dbl_p = C.POINTER(C.c_double)
+c_flt_p = C.POINTER(C.c_float)
 c_ll_p = C.POINTER(C.c_longlong)
 c_str_arr = C.POINTER(C.c_char_p)
 H = C.c_void_p
@@ -92,6 +93,11 @@ PROTOTYPES = {
     "mgb_amg_f0_trial": [H, C.c_int, c_dbl_p, c_dbl_p, C.c_double, c_dbl_p],
     "mgb_amg_f1": [H, C.c_int, c_dbl_p, C.c_double, c_dbl_p],
     "mgb_amg_f2": [H, C.c_int, c_dbl_p, C.c_double, c_dbl_p],
+    "mgb_amg_f0_f32": [H, C.c_int, c_flt_p, C.c_float, c_dbl_p],
+    "mgb_amg_f1_f32": [H, C.c_int, c_flt_p, C.c_float, c_flt_p],
+    "mgb_amg_f2_f32": [H, C.c_int, c_flt_p, C.c_float, c_flt_p],
+    "mgb_amg_f1_template_f64": [H, C.c_int, c_dbl_p, C.c_double, c_dbl_p],
+    "mgb_amg_f2_template_f64": [H, C.c_int, c_dbl_p, C.c_double, c_dbl_p],
     "mgb_amg_solve_linear": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],
     "mgb_amg_solve_linear_gpu": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],
     "mgb_amg_set_solver": [H, C.c_int],

@@ -1214,6 +1214,101 @@ void Amg::f2(int l, const double* s_host, double t, double* avals_host) {
   lv.avals.download(avals_host, lv.plan.Apat.nnz());
 }
 
+// ------------------------------------------------------------------ Float32 evaluation (kernels_f32.hip)
+void Amg::ensure_f32(Level& lv) {
+  const size_t nK = (size_t)n_ * P_.K;
+  if (w32_.n != (size_t)n_) {
+    w32_.alloc(n_);
+    c32_.alloc(nK);
+    Dz0_32_.alloc(nK);
+    Dz32_.alloc(nK);
+    v32_.alloc(nK);
+    Y32_.alloc((size_t)n_ * P_.nY());
+    rowF_.alloc(n_);
+    rowC_.alloc(n_);
+  }
+  // the row data may have changed since the last call (set_c / set_z): convert every time, it is three small launches
+  launch_to_f32(ctx_.stream, n_, w_.p, w32_.p);
+  launch_to_f32(ctx_.stream, (long long)nK, c_.p, c32_.p);
+  launch_to_f32(ctx_.stream, (long long)nK, Dz0_.p, Dz0_32_.p);
+  if (!lv.f32_built) {
+    lv.B32.alloc(lv.B.view.nnz);
+    lv.BT32.alloc(lv.BT.view.nnz);
+    lv.T32.alloc(lv.T.view.nnz);
+    launch_to_f32(ctx_.stream, lv.B.view.nnz, lv.B.view.vals, lv.B32.p);
+    launch_to_f32(ctx_.stream, lv.BT.view.nnz, lv.BT.view.vals, lv.BT32.p);
+    launch_to_f32(ctx_.stream, lv.T.view.nnz, lv.T.view.vals, lv.T32.p);
+    lv.s32.alloc(lv.plan.N);
+    lv.g32.alloc(lv.plan.N);
+    lv.avals32.alloc(lv.plan.Apat.nnz());
+    lv.f32_built = true;
+  }
+}
+
+double Amg::f0_f32(int l, const float* s_host, float t) {
+  if (ctx_.world > 1) throw ArgError("f0_f32: single-GPU contexts only");
+  Level& lv = level(l);
+  ensure_f32(lv);
+  lv.s32.upload(s_host, lv.plan.N);
+  launch_spmv_f32(ctx_.stream, lv.B.view, lv.B32.p, lv.s32.p, Dz0_32_.p, Dz32_.p);
+  launch_barrier_f0_rows_f32(ctx_.stream, n_, P_, Dz32_.p, w32_.p, c32_.p, rowF_.p, rowC_.p);
+  launch_sum(ctx_.stream, n_, rowF_.p, partials_.p, scal_.p, nullptr);
+  launch_sum(ctx_.stream, n_, rowC_.p, partials_.p, scal_.p + 1, nullptr);
+  double h[2];
+  hip_check(hipMemcpyAsync(h, scal_.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H f0_f32");
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync f0_f32");
+  return h[0] + (double)t * h[1];
+}
+
+void Amg::f1_f32(int l, const float* s_host, float t, float* g_host) {
+  if (ctx_.world > 1) throw ArgError("f1_f32: single-GPU contexts only");
+  Level& lv = level(l);
+  ensure_f32(lv);
+  lv.s32.upload(s_host, lv.plan.N);
+  launch_spmv_f32(ctx_.stream, lv.B.view, lv.B32.p, lv.s32.p, Dz0_32_.p, Dz32_.p);
+  launch_barrier_f1_f32(ctx_.stream, n_, P_, Dz32_.p, w32_.p, c32_.p, t, v32_.p);
+  launch_spmv_f32(ctx_.stream, lv.BT.view, lv.BT32.p, v32_.p, nullptr, lv.g32.p);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync f1_f32");
+  lv.g32.download(g_host, lv.plan.N);
+}
+
+void Amg::f2_f32(int l, const float* s_host, float t, float* avals_host) {
+  (void)t;
+  if (ctx_.world > 1) throw ArgError("f2_f32: single-GPU contexts only");
+  Level& lv = level(l);
+  ensure_f32(lv);
+  lv.s32.upload(s_host, lv.plan.N);
+  launch_spmv_f32(ctx_.stream, lv.B.view, lv.B32.p, lv.s32.p, Dz0_32_.p, Dz32_.p);
+  launch_barrier_f2_f32(ctx_.stream, n_, P_, Dz32_.p, w32_.p, Y32_.p);
+  launch_spmv_f32(ctx_.stream, lv.T.view, lv.T32.p, Y32_.p, nullptr, lv.avals32.p);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync f2_f32");
+  lv.avals32.download(avals_host, lv.plan.Apat.nnz());
+}
+
+// the double instantiation of the templates behind the Float32 kernels (tests: bit for bit f1 / f2 above)
+void Amg::f1_tpl64(int l, const double* s_host, double t, double* g_host) {
+  if (ctx_.world > 1) throw ArgError("f1_tpl64: single-GPU contexts only");
+  Level& lv = level(l);
+  lv.s_trial.upload(s_host, lv.plan.N);
+  launch_spmv_tpl_f64(ctx_.stream, lv.B.view, lv.s_trial.p, Dz0_.p, Dz_.p);
+  launch_barrier_f1_tpl_f64(ctx_.stream, n_, P_, Dz_.p, w_.p, c_.p, t, v_.p);
+  launch_spmv_tpl_f64(ctx_.stream, lv.BT.view, v_.p, nullptr, lv.g_trial.p);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync f1_tpl64");
+  lv.g_trial.download(g_host, lv.plan.N);
+}
+
+void Amg::f2_tpl64(int l, const double* s_host, double t, double* avals_host) {
+  (void)t;
+  if (ctx_.world > 1) throw ArgError("f2_tpl64: single-GPU contexts only");
+  Level& lv = level(l);
+  lv.s_trial.upload(s_host, lv.plan.N);
+  launch_spmv_tpl_f64(ctx_.stream, lv.B.view, lv.s_trial.p, Dz0_.p, Dz_.p);
+  launch_barrier_f2_tpl_f64(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p);
+  launch_spmv_tpl_f64(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync f2_tpl64");
+  lv.avals.download(avals_host, lv.plan.Apat.nnz());
+}
+
 void Amg::apply_D(int l, const double* s_host, double* Dz_host) {
   Level& lv = level(l);
   lv.s_trial.upload(s_host, lv.plan.N);

@@ -233,7 +233,14 @@ class Amg {
   // distance it has at s_ref
   double f0_trial(int l, const double* s_ref_host, const double* s_host, double t);
   void f1(int l, const double* s_host, double t, double* g_host);
-  void f2(int l, const double* s_host, double t, double* avals_host);   // lower-triangle values, plan(l).Apat order
+  void f2(int l, const double* s_host, double t, double* avals_host);
+  // Float32 evaluation of the same three pieces at level l (kernels_f32.hip; float operators and vectors are shadows of the
+  // double ones, built on first use).  tpl64 != 0: the double instantiation of the SAME templates instead (tests).
+  double f0_f32(int l, const float* s_host, float t);
+  void f1_f32(int l, const float* s_host, float t, float* g_host);
+  void f2_f32(int l, const float* s_host, float t, float* avals_host);
+  void f1_tpl64(int l, const double* s_host, double t, double* g_host);
+  void f2_tpl64(int l, const double* s_host, double t, double* avals_host);   // lower-triangle values, plan(l).Apat order
   void apply_D(int l, const double* s_host, double* Dz_host);          // n x K row-major
   // solve (R'HR) nstep = g with the level's multifrontal factorization; returns false if not SPD
   bool solve_host(int l, const double* avals, const double* g, double* nstep);
@@ -266,6 +273,8 @@ class Amg {
     LevelPlan plan;
     DevCsrOwned R, B, BT, T;
     DevElCsrOwned Bel;      // element-local view of B for apply_D on bandwidth-bound meshes
+    DevBuf<float> B32, BT32, T32, s32, g32, avals32;      // Float32 shadows (ensure_f32)
+    bool f32_built = false;
     MfChol chol;      // symbolic structure (+ host numeric path)
     GpuChol gchol;    // device numeric factorisation / sweeps on the same tree
     DevBuf<double> s, s_trial, s_trial2, s_trial3, g, g_trial, nstep, avals;
@@ -328,6 +337,9 @@ class Amg {
   Ctx& ctx_;
   int n_ = 0, S_ = 0;
   int ng_ = 0, r0_ = 0;           // global rows, first local row
+  DevBuf<float> w32_, c32_, Dz0_32_, Dz32_, v32_, Y32_;      // Float32 shadows of the row data
+  DevBuf<double> rowF_, rowC_;
+  void ensure_f32(Level& lv);
   BarrierParams P_;
   AmgSpec spec_;
   GeometryHost geo_;              // kept for lazy level construction

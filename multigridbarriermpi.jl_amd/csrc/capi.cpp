@@ -716,6 +716,36 @@ int mgb_amg_prepare(mgb_amg a, int level) {
     a->amg->prepare(level);
   });
 }
+int mgb_amg_f0_f32(mgb_amg a, int level, const float* s, float t, double* f0) {
+  return guard([&] {
+    need(a && s && f0 && level >= 0 && level < a->amg->L(), "f0_f32: bad arguments");
+    *f0 = a->amg->f0_f32(level, s, t);
+  });
+}
+int mgb_amg_f1_f32(mgb_amg a, int level, const float* s, float t, float* g) {
+  return guard([&] {
+    need(a && s && g && level >= 0 && level < a->amg->L(), "f1_f32: bad arguments");
+    a->amg->f1_f32(level, s, t, g);
+  });
+}
+int mgb_amg_f2_f32(mgb_amg a, int level, const float* s, float t, float* lower_vals) {
+  return guard([&] {
+    need(a && s && lower_vals && level >= 0 && level < a->amg->L(), "f2_f32: bad arguments");
+    a->amg->f2_f32(level, s, t, lower_vals);
+  });
+}
+int mgb_amg_f1_template_f64(mgb_amg a, int level, const double* s, double t, double* g) {
+  return guard([&] {
+    need(a && s && g && level >= 0 && level < a->amg->L(), "f1_template_f64: bad arguments");
+    a->amg->f1_tpl64(level, s, t, g);
+  });
+}
+int mgb_amg_f2_template_f64(mgb_amg a, int level, const double* s, double t, double* lower_vals) {
+  return guard([&] {
+    need(a && s && lower_vals && level >= 0 && level < a->amg->L(), "f2_template_f64: bad arguments");
+    a->amg->f2_tpl64(level, s, t, lower_vals);
+  });
+}
 int mgb_amg_chol_info(mgb_amg a, int level, int* split_world, double* exchange_doubles, int* launches) {
   return guard([&] {
     need(a && level >= 0 && level < a->amg->L(), "level out of range");

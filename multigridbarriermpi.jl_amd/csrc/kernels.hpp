@@ -68,6 +68,20 @@ void launch_spmv(hipStream_t st, const DevCsr& A, const double* x, const double*
 // the same product through the element-local view (bitwise the same y: per row the same lanes add the same terms in the
 // same order; only the x entries come from LDS)
 void launch_spmv_el(hipStream_t st, const DevCsr& A, const DevElCsr& E, const double* x, const double* y0, double* y);
+// ---- Float32 instantiation (csrc/kernels_f32.hip): the SpMV and barrier kernels as templates over the scalar type.  `vals` are
+// the matrix values converted to float; the index arrays are A's own.  f0 comes as per-row terms in double (w F, w <c, Dz>),
+// summed by the caller's double reduction.  The *_tpl_f64 launches run the T = double instantiation of the same templates
+// (tests: bit for bit the production kernels).
+void launch_spmv_f32(hipStream_t st, const DevCsr& A, const float* vals, const float* x, const float* y0, float* y);
+void launch_barrier_f0_rows_f32(hipStream_t st, int n, BarrierParams P, const float* Dz, const float* w, const float* c,
+                                double* outF, double* outC);
+void launch_barrier_f1_f32(hipStream_t st, int n, BarrierParams P, const float* Dz, const float* w, const float* c, float t, float* v);
+void launch_barrier_f2_f32(hipStream_t st, int n, BarrierParams P, const float* Dz, const float* w, float* Y);
+void launch_to_f32(hipStream_t st, long long n, const double* in, float* out);
+void launch_spmv_tpl_f64(hipStream_t st, const DevCsr& A, const double* x, const double* y0, double* y);
+void launch_barrier_f1_tpl_f64(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c, double t,
+                               double* v);
+void launch_barrier_f2_tpl_f64(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, double* Y);
 // out = x + alpha*y
 void launch_waxpby(hipStream_t st, int n, const double* x, double alpha, const double* y, double* out);
 // Reductions finish inside the producing launch (csrc/kernels.hip: grid_finish): `scratch` starts with

@@ -239,6 +239,47 @@ def test_barrier_kernels_match_oracle_all_levels(M, kind, L, p):
             assert np.linalg.norm(Hg @ n_g - g_g) <= 1e-10 * np.linalg.norm(g_g)     # small residual
 
 
+@pytest.mark.parametrize("kind,L,p", [("fem1d", 5, 1.5), ("fem2d", 4, 1.0), ("fem2d", 3, 2.0), ("fem3d", 2, 1.5)])
+def test_float32_kernels_match_the_oracle_and_the_double_kernels(M, kind, L, p):
+    """SURVEY.md section 8 f3 (the reference runs Float32 on its Metal backend, test/test_utils.jl:67-88): the SpMV / barrier
+    kernels instantiated for float (csrc/kernels_f32.hip) at every level -- f0, f1, f2 against the ORACLE (float64 numpy) at
+    float32 accuracy, tolerance 2e-5 relative (eps_f32 = 1.2e-7 times the growth of the row sums and of 1/phi) -- and the
+    double instantiation of the same kernel templates against the production double kernels bit for bit, which ties the
+    float kernels to the code the solve runs."""
+    A, Mo, B, z0, c, go = _problem(M, kind, L, p)
+    rng = np.random.default_rng(23)
+    t = 3.7
+    gm_sub = A.geometry.subspaces
+    for l in range(L):
+        Ro = Mo.R[l]
+        Rg = sp.block_diag([gm_sub["dirichlet"][l].host, gm_sub["full"][l].host], format="csr")
+        pi = _match_columns(Ro, Rg)
+        N = Ro.shape[1]
+        so = 2e-3 * rng.standard_normal(N)
+        sg = np.zeros(N)
+        sg[pi] = so
+        y_o = B.f0(so, Mo.x, Mo.w, t * c, Ro, Mo.D, z0)
+        g_o = B.f1(so, Mo.x, Mo.w, t * c, Ro, Mo.D, z0)
+        H_o = B.f2(so, Mo.x, Mo.w, t * c, Ro, Mo.D, z0).toarray()
+        y32 = A.f0_f32(l, sg, t)
+        g32 = A.f1_f32(l, sg, t)
+        v32 = A.f2_f32(l, sg, t)
+        assert g32.dtype == np.float32 and v32.dtype == np.float32
+        assert abs(y32 - y_o) <= 2e-5 * abs(y_o)
+        assert rel(g32[pi].astype(np.float64), g_o) < 2e-5
+        rp, ci = A.hessian_pattern(l)
+        Lo = sp.csr_matrix((v32.astype(np.float64), ci, rp), shape=(N, N))
+        H32 = (Lo + sp.tril(Lo, -1).T).toarray()[np.ix_(pi, pi)]
+        assert np.abs(H32 - H_o).max() <= 2e-5 * np.abs(H_o).max()
+        # the same templates, T = double: the production kernels, bit for bit
+        assert np.array_equal(A.f1_template_f64(l, sg, t), A.f1(l, sg, t))
+        assert np.array_equal(A.f2_template_f64(l, sg, t), A.f2(l, sg, t)[1])
+        # and float really is float: it differs from the double result, but only at float accuracy
+        g64 = A.f1(l, sg, t)
+        d = rel(g32.astype(np.float64), g64)
+        assert 0 < d < 2e-5
+
+
 def test_infeasible_trial_is_reported_not_raised(M):
     """amgb_all_isfinite semantics (src:121-133): an infeasible line-search trial is a status."""
     A, Mo, B, z0, c, go = _problem(M, "fem2d", 2, 1.0)
