@@ -192,6 +192,10 @@ int mgb_amg_set_solver(mgb_amg a, int host);
 int mgb_amg_set_schedule(mgb_amg a, int all_levels);
 /* amgb main phase: t-continuation x level loop x Newton; z updated in place */
 int mgb_amg_solve(mgb_amg a, double tol, double t0, double kappa, int maxit, int max_newton, int verbose);
+/* feasibility phases (SOL_feasibility, src:428-455): make mgb_amg_solve return after the first centering at which row `col`
+ * of D z -- the slack of a relaxed problem -- is negative at every node, instead of following the path to t = 1/tol.
+ * col = -1 (default): off. */
+int mgb_amg_set_early_stop(mgb_amg a, int col);
 /* SOL_main fields (docs/src/api.md:97-101) of the last mgb_amg_solve */
 int mgb_amg_sol_info(mgb_amg a, int* nt, double* t_elapsed, double* time_factor, long long* counts4);
 int mgb_amg_sol_get(mgb_amg a, long long* its /* L x nt col-major */, double* ts, double* c_dot_Dz);

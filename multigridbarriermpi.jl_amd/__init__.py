@@ -1003,6 +1003,45 @@ class AMGBSOL:
     geometry: Geometry
 
 
+PHASE1_SLACK_FLOOR = 1.0
+PHASE1_PENALTY = 10.0
+
+
+def _phase1_slack(geometry, M: "AMG", p, z0, c, tol, schedule, solver):
+    """General feasibility phase (oracle amgb_phase1_slack; upstream amgb_phase1, SOL_feasibility src:428-455): the original
+    problem relaxed by a slack field sigma (:full subspace, one more row `sigma id` of D) -- (q, s + sigma) in the power cone,
+    coef . y + off + sigma > 0 for the half space, sigma > -1 -- with the penalty PHASE1_PENALTY max(1, |c|_max) on sigma,
+    started strictly inside at sigma0 = 1 + the largest violation and path-followed on the device until sigma < 0 at every
+    node (mgb_amg_set_early_stop).  Returns the strictly feasible (n, S) start of the main phase and the SOL fields."""
+    n, S = z0.shape
+    K = len(M.D)
+    cone, extras = M.cones[0], list(M.cones[1:])
+    if len(extras) > 1 or cone[0] == "linear":
+        raise NotImplementedError("amgb: the feasibility phase covers the power cone intersected with one half space")
+    state1 = tuple(M.state_variables) + (("sigma", "full"),)
+    D1 = tuple(M.D) + (("sigma", "id"),)
+    terms = [(list(cone[0]), cone[1], K)]
+    terms += [("linear", list(e[1]) + [K], list(map(float, e[2])) + [1.0], float(e[3])) for e in extras]
+    terms.append(("linear", [K], [1.0], PHASE1_SLACK_FLOOR))
+    Dz = M.apply_D_global(M.L - 1, np.zeros(M.level_size(M.L - 1)[0]))
+    idx = list(cone[0])
+    viol = [np.sum(Dz[:, idx[:-1]] ** 2, axis=1) ** (cone[1] / 2.0) - Dz[:, idx[-1]]]
+    viol += [-(Dz[:, list(e[1])] @ np.asarray(e[2], dtype=np.float64) + float(e[3])) for e in extras]
+    sigma0 = 1.0 + max(0.0, float(np.max(np.concatenate(viol))))
+    M1 = AMG(geometry, state1, D1, p, cones=terms)
+    c1 = np.column_stack([c, np.full(n, PHASE1_PENALTY * max(1.0, float(np.max(np.abs(c)))))])
+    M1.set_c(c1)
+    M1.set_z(np.column_stack([z0, np.full(n, sigma0)]).reshape(-1, order="F"))
+    call("mgb_amg_set_early_stop", M1.handle, K)
+    M1.prepare()
+    SOL = M1.solve(tol=tol, schedule=schedule, solver=solver)
+    z1 = M1.get_z().reshape((n, S + 1), order="F")
+    if not np.max(z1[:, S]) < 0.0:
+        raise MGBError(-3, "amgb: the problem is infeasible (the feasibility phase ended with a non-negative slack)")
+    SOL["sigma0"] = sigma0
+    return np.ascontiguousarray(z1[:, :S]), SOL
+
+
 def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=None, g=None, tol=None, t=0.1,
          maxit=10000, kappa=10.0, verbose=False, logfile=None, schedule="fine", solver="gpu", cones=None, **rest) -> AMGBSOL:
     """MultiGridBarrier.amgb on an MPI geometry (called at src:599,666).  kwargs as documented in
@@ -1028,21 +1067,28 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
         # the slack row is `id` of a :full state variable (that space contains the constants), so a constant
         # shift sigma = 1 + max(|q|^p - s) of that variable is strictly feasible.  Dz comes from the device.
         idx = M.idx
-        if not idx or len(M.cones) != 1:
-            raise MGBError(-3, "amgb: infeasible start (the closed-form feasibility phase covers a single power cone only)")
-        var, op = M.D[idx[-1]]
-        names = [sv[0] for sv in M.state_variables]
-        if op != "id" or dict(M.state_variables)[var] != "full":
-            raise NotImplementedError("amgb: feasibility phase needs the cone's slack to be `id` of a :full variable")
-        Dz = M.apply_D_global(M.L - 1, np.zeros(Nf))
-        q2 = np.sum(Dz[:, idx[:-1]] ** 2, axis=1)
-        sigma = 1.0 + float(np.max(q2 ** (p / 2.0) - Dz[:, idx[-1]]))
-        z0[:, names.index(var)] += sigma
-        M.set_z(z0.reshape(-1, order="F"))
-        if not math.isfinite(M.f0(M.L - 1, np.zeros(Nf), 0.0)):
-            raise MGBError(-3, "amgb: feasibility phase failed")
-        SOL_feasibility = dict(shift=sigma, its=np.zeros((M.L, 0), dtype=np.int64), ts=np.zeros(0),
-                               c_dot_Dz=np.zeros(0), t_elapsed=0.0)
+        if idx and len(M.cones) > 1:
+            # general feasibility phase: the set relaxed by a slack field, path-followed until the slack is negative
+            z0, SOL_feasibility = _phase1_slack(geometry, M, p, z0, c, tol, schedule, solver)
+            M.set_z(z0.reshape(-1, order="F"))
+            if not math.isfinite(M.f0(M.L - 1, np.zeros(Nf), 0.0)):
+                raise MGBError(-3, "amgb: feasibility phase failed")
+        elif not idx:
+            raise MGBError(-3, "amgb: infeasible start")
+        else:
+            var, op = M.D[idx[-1]]
+            names = [sv[0] for sv in M.state_variables]
+            if op != "id" or dict(M.state_variables)[var] != "full":
+                raise NotImplementedError("amgb: feasibility phase needs the cone's slack to be `id` of a :full variable")
+            Dz = M.apply_D_global(M.L - 1, np.zeros(Nf))
+            q2 = np.sum(Dz[:, idx[:-1]] ** 2, axis=1)
+            sigma = 1.0 + float(np.max(q2 ** (p / 2.0) - Dz[:, idx[-1]]))
+            z0[:, names.index(var)] += sigma
+            M.set_z(z0.reshape(-1, order="F"))
+            if not math.isfinite(M.f0(M.L - 1, np.zeros(Nf), 0.0)):
+                raise MGBError(-3, "amgb: feasibility phase failed")
+            SOL_feasibility = dict(shift=sigma, its=np.zeros((M.L, 0), dtype=np.int64), ts=np.zeros(0),
+                                   c_dot_Dz=np.zeros(0), t_elapsed=0.0)
     M.prepare()       # factorisation structures are setup, not solve time (SOL_main.t_elapsed mirrors the reference's)
     SOL = M.solve(tol=tol, t=t, kappa=kappa, maxit=maxit, verbose=2 if verbose and verbose > 1 else int(bool(verbose)),
                   schedule=schedule, solver=solver)

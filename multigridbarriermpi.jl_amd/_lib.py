@@ -93,6 +93,7 @@ PROTOTYPES = {
     "mgb_amg_f0_trial": [H, C.c_int, c_dbl_p, c_dbl_p, C.c_double, c_dbl_p],
     "mgb_amg_f1": [H, C.c_int, c_dbl_p, C.c_double, c_dbl_p],
     "mgb_amg_f2": [H, C.c_int, c_dbl_p, C.c_double, c_dbl_p],
+    "mgb_amg_set_early_stop": [H, C.c_int],
     "mgb_amg_f0_f32": [H, C.c_int, c_flt_p, C.c_float, c_dbl_p],
     "mgb_amg_f1_f32": [H, C.c_int, c_flt_p, C.c_float, c_flt_p],
     "mgb_amg_f2_f32": [H, C.c_int, c_flt_p, C.c_float, c_flt_p],

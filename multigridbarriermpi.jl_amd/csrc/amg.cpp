@@ -1103,6 +1103,21 @@ double Amg::c_dot_dz() {
   return h_scal_.p[1];
 }
 
+// early stop of a feasibility phase: is column early_stop_col_ of the accepted Dz negative at every node (of every rank)?
+bool Amg::slack_negative() {
+  std::vector<double> h((size_t)n_ * P_.K);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync early stop");
+  Dz0_.download(h.data(), h.size());
+  double bad = 0;
+  for (int q = 0; q < n_; ++q) bad += (h[(size_t)q * P_.K + early_stop_col_] < 0.0) ? 0.0 : 1.0;
+  if (ctx_.world > 1) {
+    hip_check(hipMemcpy(scal_.p, &bad, sizeof(double), hipMemcpyHostToDevice), "H2D early stop");
+    ctx_.allreduce_sum(scal_.p, 1);
+    hip_check(hipMemcpy(&bad, scal_.p, sizeof(double), hipMemcpyDeviceToHost), "D2H early stop");
+  }
+  return bad == 0.0;
+}
+
 void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
   const int L = (int)levels_.size();
@@ -1141,7 +1156,9 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   // otherwise the last t, and with it z to ~1e-6, depends on the rounding-sensitive history of kappa reductions)
   double t_stop = t;
   while (t_stop <= 1 / opt.tol) t_stop *= kappa0;
-  while (t < t_stop && kappa > 1 && k < opt.maxit) {
+  if (early_stop_col_ >= P_.K) throw ArgError("amgb: early-stop column out of range");
+  bool stopped = early_stop_col_ >= 0 && slack_negative();
+  while (t < t_stop && kappa > 1 && k < opt.maxit && !stopped) {
     k++;
     std::fill(its.begin(), its.end(), 0);
     while (kappa > 1) {
@@ -1172,10 +1189,11 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
     st.c_dot_Dz.push_back(c_dot_dz());
     if (opt.verbose)
       fprintf(stderr, "[mgb] t=%.4g kappa=%.3g its(finest)=%lld c.Dz=%.12g\n", t, kappa, its[L - 1], st.c_dot_Dz.back());
+    stopped = early_stop_col_ >= 0 && slack_negative();
   }
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   st.t_elapsed = now_s() - t_begin;
-  if (t < t_stop) throw NumericError("amgb: convergence failure (kappa collapsed)");
+  if (t < t_stop && !stopped) throw NumericError("amgb: convergence failure (kappa collapsed)");
 }
 
 // ------------------------------------------------------------------ fine-grained entry points

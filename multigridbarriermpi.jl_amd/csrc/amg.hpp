@@ -220,6 +220,9 @@ class Amg {
   // device factorisation of level l: ranks it is split over (1 = replicated), doubles exchanged per solve, launches
   void chol_info(int l, int* split_world, double* exchange_doubles, int* launches);
   bool chol_values_local(int l) { return values_stay_local(level(l)); }
+  // feasibility phases: stop the continuation after the first centering at which row `col` of Dz is negative at every node
+  // (col < 0: off).  The solve then returns normally with fewer t-steps instead of running to t_stop.
+  void set_early_stop(int col) { early_stop_col_ = col; }
 
   // problem data: c is n x K row-major, z is the S*n vector [u; s]
   void set_c(const double* c_host);
@@ -337,6 +340,8 @@ class Amg {
   Ctx& ctx_;
   int n_ = 0, S_ = 0;
   int ng_ = 0, r0_ = 0;           // global rows, first local row
+  int early_stop_col_ = -1;
+  bool slack_negative();
   DevBuf<float> w32_, c32_, Dz0_32_, Dz32_, v32_, Y32_;      // Float32 shadows of the row data
   DevBuf<double> rowF_, rowC_;
   void ensure_f32(Level& lv);

@@ -716,6 +716,12 @@ int mgb_amg_prepare(mgb_amg a, int level) {
     a->amg->prepare(level);
   });
 }
+int mgb_amg_set_early_stop(mgb_amg a, int col) {
+  return guard([&] {
+    need(a && col >= -1, "set_early_stop: bad arguments");
+    a->amg->set_early_stop(col);
+  });
+}
 int mgb_amg_f0_f32(mgb_amg a, int level, const float* s, float t, double* f0) {
   return guard([&] {
     need(a && s && f0 && level >= 0 && level < a->amg->L(), "f0_f32: bad arguments");

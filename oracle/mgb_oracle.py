@@ -840,8 +840,8 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
     log = [] if keep_log else None
     SOL_feas = None
     if extra and not np.all(np.isfinite(B.Q.F(x, Dz))):
-        raise RuntimeError("amgb: infeasible start (the closed-form feasibility phase covers a single power cone only)")
-    if not np.all(np.isfinite(Q.F(x, Dz))):
+        zvec, SOL_feas = amgb_phase1_slack(geometry, state_variables, M.Dspec, Q, extra, zvec, Dz, tol, schedule, c=c)
+    elif not np.all(np.isfinite(Q.F(x, Dz))):
         zvec, SOL_feas = amgb_phase1(geometry, state_variables, M.Dspec, Q, zvec, Dz, tol, schedule)
     SOL = amgb_core(B, M, zvec, c, tol, t=t, maxit=maxit, kappa=kappa, log=log, schedule=schedule)
     z = SOL.pop("z").reshape(z0.shape, order="F")
@@ -868,6 +868,48 @@ def amgb_phase1(geometry, state_variables, D, Q: PowerConeBarrier, zvec, Dz, tol
     L = len(geometry.refine)
     SOL = dict(shift=sigma, its=np.zeros((L, 0), dtype=np.int64), ts=np.zeros(0), c_dot_Dz=np.zeros(0), t_elapsed=0.0)
     return z, SOL
+
+
+PHASE1_SLACK_FLOOR = 1.0      # the slack field of the general feasibility phase lives in sigma > -PHASE1_SLACK_FLOOR
+PHASE1_PENALTY = 10.0         # ... and costs this many times the largest original cost coefficient
+
+
+def amgb_phase1_slack(geometry, state_variables, D, Q: PowerConeBarrier, extra, zvec, Dz, tol, schedule=None, c=None):
+    """General feasibility phase for the cone intersected with half spaces (upstream amgb_phase1: a barrier solve on the
+    convex set relaxed by a slack, stopped as soon as the slack is negative; [UPSTREAM-UNVERIFIED] in its details --
+    nothing in the reference pins them -- so this is the phase both this oracle and the HIP path implement):
+        state (.., sigma) with sigma in the :full subspace, D' = D + [sigma id], minimise  int c . Dz + M sigma  subject to
+        (q, s + sigma) in the power cone,  coef . y + off + sigma > 0  for every half space,  sigma > -1,
+    from sigma0 = 1 + the largest violation (strictly feasible), path-followed by amgb_core and stopped after the first
+    centering with sigma < 0 everywhere: the point then lies strictly inside the original set.  It is the original problem
+    relaxed by the slack with the penalty M = PHASE1_PENALTY max(1, |c|_max) on it ("big M"): the original cost keeps the
+    cone slack s bounded (with cost on sigma alone the barrier runs off along s -> infinity), M > c_s makes trading sigma
+    for s pay until sigma reaches its floor, and the floor sigma > -1 bounds the problem below."""
+    n = geometry.x.shape[0]
+    K = Dz.shape[1]
+    if len(extra) > 1:
+        raise NotImplementedError("feasibility phase: one half space (three barrier terms in all)")
+    state1 = tuple(state_variables) + (("sigma", "full"),)
+    D1 = tuple(D) + (("sigma", "id"),)
+    M1 = amg(geometry, state1, D1)
+    Q1 = PowerConeBarrier(tuple(Q.idx), Q.p, idx_s2=K)
+    terms = [Q1] + [LinearBarrier(list(e.idx) + [K], list(e.coef) + [1.0], e.off) for e in extra]
+    terms.append(LinearBarrier([K], [1.0], PHASE1_SLACK_FLOOR))
+    B1 = Barrier(ConeIntersection(terms))
+    q, sl = Q._qs(Dz)
+    viol = [np.sum(q * q, axis=1) ** (Q.p / 2.0) - sl] + [-e.phi(Dz) for e in extra]
+    sigma0 = 1.0 + max(0.0, float(np.max(np.concatenate(viol))))
+    z1 = np.concatenate([zvec, np.full(n, sigma0)])
+    c1 = np.zeros((n, K + 1))
+    if c is not None:
+        c1[:, :K] = c
+    c1[:, K] = PHASE1_PENALTY * max(1.0, float(np.max(np.abs(c1[:, :K]))))
+    SOL = amgb_core(B1, M1, z1, c1, tol, schedule=schedule, early_stop=lambda Dz0: bool(np.max(Dz0[:, K]) < 0.0))
+    z = SOL.pop("z")
+    if not np.max(z[len(zvec):]) < 0.0:
+        raise RuntimeError("amgb: the problem is infeasible (the feasibility phase ended with a non-negative slack)")
+    SOL["sigma0"] = sigma0
+    return z[:len(zvec)], SOL
 
 
 @dataclass

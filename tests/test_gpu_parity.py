@@ -657,6 +657,38 @@ def test_solve_matches_live_oracle_on_multi_panel_meshes(M, kind, L, p, tol):
     assert rel(z, zo) < tol
 
 
+@pytest.mark.parametrize("kind,L,p", [("fem1d", 4, 1.5), ("fem2d", 3, 1.5), ("fem2d", 4, 1.0)])
+def test_general_feasibility_phase_matches_oracle(M, kind, L, p):
+    """SOL_feasibility (src:428-455) beyond the closed-form shift: the start u0 dips below the obstacle u > -0.2 inside the
+    domain AND its cone slack is too small, so neither set is satisfied.  Both sides run the same phase 1 -- the problem
+    relaxed by a slack field with a big-M penalty, path-followed until the slack is negative everywhere (oracle
+    amgb_phase1_slack; device: one more state variable and D row, mgb_amg_set_early_stop) -- and then the main phase:
+    same number of phase-1 centerings, z of the whole solve at 1e-10."""
+    dim = 1 if kind == "fem1d" else 2
+    f = (lambda x: np.array([0.5, 0.0, 1.0])) if dim == 1 else (lambda x: np.array([0.5, 0.0, 0.0, 1.0]))
+    g = lambda x: np.array([1.0 - 1.5 * (1.0 - float(np.sum(np.asarray(x) ** 2)) / dim), 0.05])
+    gm = getattr(M, kind + "_mpi")(L)
+    go = getattr(O, kind)(L)
+    cone = (list(range(1, dim + 2)), p)
+    lin = ("linear", [0], [1.0], 0.2)
+    u0 = np.array([g(xi)[0] for xi in go.x])
+    assert u0.min() < -0.2                                                   # the start violates the obstacle
+    sol = M.amgb(gm, p=p, f=f, g=g, cones=[cone, lin])
+    ref = O.amgb(go, p=p, f=f, g=g, extra=[O.LinearBarrier([0], [1.0], 0.2)])
+    Fg, Fo = sol.SOL_feasibility, ref.SOL_feasibility
+    assert Fg is not None and Fo is not None
+    assert abs(Fg["sigma0"] - Fo["sigma0"]) <= 1e-12 * Fo["sigma0"]
+    assert np.allclose(Fg["ts"], Fo["ts"], rtol=1e-12) and len(Fg["ts"]) >= 2           # stopped early, on the same centering
+    z = M.mpi_to_native(sol).z
+    # u at 1e-10; the cone slack s (1e-4 .. 3 here) carries the resolution of the Newton stop rule (see LARGE_END_POINT_TOL):
+    # 1.2e-10 measured on fem2d L=3, the two main phases start from phase-1 points that differ in the last bits
+    assert rel(z[:, 0], ref.z[:, 0]) < ZTOL and rel(z, ref.z) < 1e-9
+    assert z[:, 0].min() > -0.2
+    # an infeasible PROBLEM (obstacle above the Dirichlet data on the boundary) is reported, not looped on
+    with pytest.raises(M.MGBError):
+        M.amgb(gm, p=p, f=f, g=g, cones=[cone, ("linear", [0], [1.0], -5.0)])
+
+
 def test_map_rows_recognises_the_barrier_family(M):
     """`map_rows(F | F1 | F2, x, Dz)` with the row functions of a convex set runs on the device
     (mgb_map_rows_barrier: the fused kernels of the Newton path with unit weights) and equals the oracle's row maps; any other

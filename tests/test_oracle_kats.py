@@ -233,3 +233,21 @@ def test_feasibility_phase_oracle():
     ok = O.amgb(O.fem2d(2), p=1.5)
     assert bad.SOL_feasibility is not None and ok.SOL_feasibility is None
     assert np.linalg.norm(bad.z - ok.z) / np.linalg.norm(ok.z) < 1e-9
+
+
+def test_oracle_general_feasibility_phase():
+    """The slack feasibility phase of the oracle (amgb_phase1_slack; [UPSTREAM-UNVERIFIED] in its details, SOL_feasibility
+    src:428-455): from a start outside both the obstacle and the cone it stops early with a negative slack, the main phase
+    then runs to t = 1/tol, and an impossible obstacle is reported."""
+    import pytest
+    g = O.fem1d(4)
+    f = lambda x: np.array([0.5, 0.0, 1.0])
+    gg = lambda x: np.array([1.0 - 1.5 * (1.0 - float(x[0] ** 2)), 0.05])
+    sol = O.amgb(g, p=1.5, f=f, g=gg, extra=[O.LinearBarrier([0], [1.0], 0.2)])
+    F = sol.SOL_feasibility
+    assert F is not None and 2 <= len(F["ts"]) < 6 and F["sigma0"] > 1.0          # stopped early: t never got near 1/tol
+    assert sol.SOL_main["ts"][-1] > 1e7 and sol.z[:, 0].min() > -0.2
+    q = g.operators["dx"] @ sol.z[:, 0]
+    assert np.all(sol.z[:, 1] > np.abs(q) ** 1.5)
+    with pytest.raises(RuntimeError):
+        O.amgb(g, p=1.5, f=f, g=gg, extra=[O.LinearBarrier([0], [1.0], -5.0)])
