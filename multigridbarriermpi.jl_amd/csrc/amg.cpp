@@ -190,7 +190,15 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
   LevelPlan pl;
   const int n = g.n, K = P.K;
   std::vector<const Csr*> subs;
+  // "fixed": a state variable without unknowns (n x 0 block of R) -- data the barrier reads through a row of D but the
+  // solve never moves, e.g. an x-dependent obstacle psi(x) in  u - psi > 0.  Not a key of Geometry.subspaces (the
+  // reference's geometries have :dirichlet and :full only), so it is recognised here
+  const Csr fixed_block(n, 0);
   for (auto& sv : spec.state_variables) {
+    if (sv.second == "fixed") {
+      subs.push_back(&fixed_block);
+      continue;
+    }
     auto it = g.subspaces.find(sv.second);
     if (it == g.subspaces.end()) throw ArgError("amg: unknown subspace '" + sv.second + "'");
     if (level < 0 || level >= (int)it->second.size()) throw ArgError("amg: level out of range");
@@ -446,6 +454,7 @@ Amg::Amg(Ctx& ctx, const GeometryHost& g, const AmgSpec& spec, const BarrierPara
     levels_.emplace_back(new Level);
     int N = 0;
     for (auto& sv : spec.state_variables) {
+      if (sv.second == "fixed") continue;      // no unknowns (build_level_plan)
       auto it = g.subspaces.find(sv.second);
       if (it == g.subspaces.end() || l >= (int)it->second.size())
         throw ArgError("amg: unknown subspace '" + sv.second + "'");

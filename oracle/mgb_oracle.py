@@ -417,7 +417,10 @@ def amg(geometry: Geometry, state_variables=DEFAULT_STATE, D=None) -> AMG:
     n = geometry.x.shape[0]
     L = len(geometry.refine)
     names = [sv[0] for sv in state_variables]
-    R = [sp.block_diag([geometry.subspaces[sv[1]][l] for sv in state_variables], format="csr") for l in range(L)]
+    # "fixed": a state variable without unknowns (n x 0 block) -- data the barrier reads through a row of D, e.g. an
+    # x-dependent obstacle; not a key of geometry.subspaces (the reference's geometries have :dirichlet / :full only)
+    blk = lambda name, l: sp.csr_matrix((n, 0)) if name == "fixed" else geometry.subspaces[name][l]
+    R = [sp.csr_matrix(sp.block_diag([blk(sv[1], l) for sv in state_variables], format="csr")) for l in range(L)]
     Z = sp.csr_matrix((n, n))
     Dm = []
     for var, op in D:
@@ -822,8 +825,9 @@ class AMGBSOL:
 
 def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=None, g=None,
          tol=None, t=0.1, maxit=10000, kappa=10.0, verbose=False, logfile=None, keep_log=False,
-         schedule=None, extra=()) -> AMGBSOL:
-    """`extra`: further convex sets intersected with the p-Laplace power cone (upstream `intersect`), e.g. LinearBarrier."""
+         schedule=None, extra=(), cone_idx=None) -> AMGBSOL:
+    """`extra`: further convex sets intersected with the p-Laplace power cone (upstream `intersect`), e.g. LinearBarrier;
+    `cone_idx`: the rows (q.., s) of D the power cone acts on (default: the last dim + 1 rows)."""
     dim = geometry.discretization["dim"]
     f = DEFAULT_F[dim] if f is None else f
     g = DEFAULT_G[dim] if g is None else g
@@ -833,7 +837,8 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
     z0 = map_rows(lambda xi: g(xi), x)           # (n, S)
     c = map_rows(lambda xi: f(xi), x)            # (n, K)
     nD = len(M.D)
-    Q = convex_Euclidian_power(idx=list(range(1, dim + 2)) if nD == dim + 2 else list(range(nD - dim - 1, nD)), p=p)
+    Q = convex_Euclidian_power(idx=list(cone_idx) if cone_idx is not None else
+                               (list(range(1, dim + 2)) if nD == dim + 2 else list(range(nD - dim - 1, nD))), p=p)
     B = Barrier(ConeIntersection([Q, *extra]) if extra else Q)
     zvec = z0.reshape(-1, order="F")
     Dz = B.apply_D(M.D, zvec)

@@ -657,6 +657,29 @@ def test_solve_matches_live_oracle_on_multi_panel_meshes(M, kind, L, p, tol):
     assert rel(z, zo) < tol
 
 
+@pytest.mark.parametrize("L,p", [(3, 1.5), (4, 1.0), (4, 2.0)])
+def test_x_dependent_obstacle_matches_oracle(M, L, p):
+    """Barrier menu: an obstacle that varies in space, u > psi(x).  psi enters as a state variable WITHOUT
+    unknowns (subspace "fixed": an n x 0 block of R) read through one more row `psi id` of D, so the half space
+    1 u - 1 psi > 0 is the constant-coefficient term the kernels already have; the solve never moves psi.  Load 5 pushes u
+    from its boundary value 1 onto the paraboloid 0.6 - 2 |x|^2: the contact set is non-trivial.  z against the oracle."""
+    state = (("u", "dirichlet"), ("s", "full"), ("psi", "fixed"))
+    D = (("u", "id"), ("u", "dx"), ("u", "dy"), ("s", "id"), ("psi", "id"))
+    psi = lambda x: 0.6 - 2.0 * float(x[0] ** 2 + x[1] ** 2)
+    f = lambda x: np.array([5.0, 0.0, 0.0, 1.0, 0.0])
+    g = lambda x: np.array([1.0, 10.0, psi(x)])
+    gm, go = M.fem2d_mpi(L), O.fem2d(L)
+    sol = M.amgb(gm, p=p, state_variables=state, D=D, f=f, g=g, cones=[([1, 2, 3], p), ("linear", [0, 4], [1.0, -1.0], 0.0)])
+    ref = O.amgb(go, p=p, state_variables=state, D=D, f=f, g=g, extra=[O.LinearBarrier([0, 4], [1.0, -1.0], 0.0)],
+                 cone_idx=[1, 2, 3])
+    z = M.mpi_to_native(sol).z
+    assert z.shape == ref.z.shape == (go.x.shape[0], 3)
+    assert np.array_equal(z[:, 2], np.array([psi(x) for x in go.x]))          # the obstacle is data: untouched, bit for bit
+    assert rel(z[:, 0], ref.z[:, 0]) < ZTOL and rel(z, ref.z) < 1e-9          # (slack column: stop-rule resolution, as above)
+    gap = z[:, 0] - z[:, 2]
+    assert gap.min() > 0 and gap.min() < 1e-6 and (gap < 1e-4).sum() > 5       # strictly above, and in contact on a set of nodes
+
+
 @pytest.mark.parametrize("kind,L,p", [("fem1d", 4, 1.5), ("fem2d", 3, 1.5), ("fem2d", 4, 1.0)])
 def test_general_feasibility_phase_matches_oracle(M, kind, L, p):
     """SOL_feasibility (src:428-455) beyond the closed-form shift: the start u0 dips below the obstacle u > -0.2 inside the
