@@ -185,8 +185,9 @@ int mgb_amg_solve_linear(mgb_amg a, int level, const double* lower_vals, const d
 /* the same solve with the device multifrontal Cholesky (csrc/gpuchol.hip): the solver the Newton loop uses
  * by default.  Returns MGB_E_NUMERIC if a pivot is not positive. */
 int mgb_amg_solve_linear_gpu(mgb_amg a, int level, const double* lower_vals, const double* g, double* x);
-/* Newton linear solver: 0 (default) = GPU multifrontal Cholesky, 1 = host multifrontal Cholesky */
-int mgb_amg_set_solver(mgb_amg a, int host);
+/* Newton linear solver: 0 (default) = GPU multifrontal Cholesky, 1 = host multifrontal Cholesky, 2 = conjugate gradients
+ * preconditioned by a V-cycle over the AMG levels, H applied matrix-free (single-GPU contexts; see the multigrid block below) */
+int mgb_amg_set_solver(mgb_amg a, int solver);
 /* amgb_step level schedule: 0 (default) = Newton on the finest subspace only, 1 = literal coarse -> fine
  * level loop (R_1 ... R_L).  Both end at the same z; see DESIGN.md section 2. */
 int mgb_amg_set_schedule(mgb_amg a, int all_levels);
@@ -213,7 +214,42 @@ int mgb_amg_sol_kernels(mgb_amg a, double* ms11, double* bytes11, long long* lau
  * launch-bound meshes), apply_D through the plain CSR kernel; bytes8[7] = 1 if slot 0 used the element-local view */
 int mgb_amg_time_kernels(mgb_amg a, int level, int reps, int nrot, double* ms8, double* bytes8);
 
+/* ---- multigrid pieces: SURVEY.md section 8 row a11 / 8(b) `mgb_hessian_apply / mgb_smooth / mgb_prolong / mgb_restrict` ------ *
+ * The reference has no smoother: its "multigrid" is Newton on the nested subspaces R_l with MultiGridBarrier.solve -> MUMPS per
+ * level (test/test_instrumented_solve.jl:25-28,99; README.md:23).  BASELINE.json's north star asks for prolongation /
+ * restriction / smoother on the GPU; they replace nothing one-to-one and serve solver 2 above, which solves the SAME Newton
+ * system H n = g (H = R_l' (sum_jk D_j' diag(w y_jk) D_k) R_l, test/test_map_rows_compare.jl:102-123,165-170) iteratively.
+ * All take host arrays like mgb_amg_f1 / f2; `s` = the point (N_l subspace coordinates) whose Hessian is meant. */
+/* Hv = H(s) v at `level`.  matrix_free != 0: B' (Y o (B v)) element by element -- the element's v and Y staged in LDS, the
+ * per-node K x K block applied in registers between the two halves (csrc/mg.hip: elop_apply_kernel); 0: through the assembled
+ * matrix (full symmetric CSR).  Both must agree with mgb_amg_f2's matrix times v. */
+int mgb_hessian_apply(mgb_amg a, int level, const double* s, const double* v, double* Hv, int matrix_free);
+/* `sweeps` Chebyshev-Jacobi passes on H(s) x = b from the given x (in/out), each `degree` (1..7) applications of H; eigenvalue
+ * interval [lo, hi] * lambda with lambda = lmax if lmax > 0, else lambda_max(Dinv H) estimated on the device (power steps in the
+ * D inner product); *lmax_used (nullable) = the lambda the coefficients were built from. */
+int mgb_smooth(mgb_amg a, int level, const double* s, const double* b, double* x, int degree, int sweeps, double lmax,
+               int matrix_free, double* lmax_used);
+/* transfer between the unknowns of level and level + 1 (R_level = R_{level+1} P): xf = P xc, rc = P' rf */
+int mgb_prolong(mgb_amg a, int level, const double* xc, double* xf);
+int mgb_restrict(mgb_amg a, int level, const double* rf, double* rc);
+/* P of `level` as CSR: sizes first (null arrays), then the arrays */
+int mgb_amg_prolongation(mgb_amg a, int level, int* rows, int* cols, int* nnz, int32_t* rowptr, int32_t* colidx, double* vals);
+/* x = H(s)^{-1} g by the V-cycle-preconditioned CG the Newton loop runs with solver 2; *converged = 0 if it stopped at maxit */
+int mgb_amg_pcg_solve_linear(mgb_amg a, int level, const double* s, const double* g, double* x, int* iters, double* relres,
+                             int* converged);
+/* CG / V-cycle parameters (a value <= 0, or < 0 for the two flags, keeps the current one): relative tolerance on
+ * sqrt(<r, M r>), iteration cap, applications of H per Chebyshev pre-/post-smoothing, power steps per level and Newton matrix,
+ * Chebyshev interval fractions, CG iterations enqueued between two looks at the convergence flag, direct solve of a step whose
+ * CG did not converge, top level through its assembled matrix instead of the matrix-free product */
+int mgb_amg_set_pcg(mgb_amg a, double rtol, int maxit, int degree, int power_its, double lo_frac, double hi_frac, int chunk,
+                    int fallback, int assembled_top);
+/* of the last mgb_amg_solve with solver 2: counts3 = {Newton systems, CG iterations, direct fallbacks}, seconds inside CG */
+int mgb_amg_sol_pcg(mgb_amg a, long long* counts3, double* time_s);
+/* coarsest level of the V-cycle whose top is level `top` (the largest level with at most 128 unknowns; dense inverse there) */
+int mgb_amg_mg_info(mgb_amg a, int top, int* coarsest);
+
 /* ---- host-only symbolic helpers (no GPU needed; used by the CPU test-suite) ----------------- */
+
 typedef struct mgb_plan_s* mgb_plan;  /* symbolic products of one level: R, B=D*R, B', Hessian plan T */
 int mgb_plan_create(mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D, int nq,
                     const int* idx_q, int idx_s, int level, mgb_plan* out);
@@ -221,6 +257,9 @@ int mgb_plan_create(mgb_geo g, int S, const char* const* state_vars, int K, cons
  * Newton unknowns per level allocates; the CPU suite checks it covers the 8-rank, 3-state-variable configurations */
 int mgb_reduction_scratch_doubles(int n_local, int max_level_unknowns, long long* out);
 int mgb_plan_destroy(mgb_plan p);
+/* host-only: P with R_fine P = R_coarse from two level plans (what mgb_prolong applies); sizes first, then the arrays */
+int mgb_plan_prolongation(mgb_plan fine, mgb_plan coarse, int* rows, int* cols, int* nnz, int32_t* rowptr, int32_t* colidx,
+                          double* vals);
 int mgb_plan_sizes(mgb_plan p, int* N, int* nnz_lower, int* nnz_T, int* nnz_B);
 int mgb_plan_pattern(mgb_plan p, int32_t* rowptr, int32_t* colidx);
 /* lower_vals = T * vec(Y) evaluated on the host: checks the plan against the reference's Hessian

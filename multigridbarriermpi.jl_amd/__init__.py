@@ -939,14 +939,78 @@ class AMG:
              dptr(lower_vals), dptr(g), dptr(x))
         return x
 
+    SOLVERS = {"gpu": 0, "host": 1, "pcg": 2}
+
+    def set_solver(self, solver="gpu"):
+        """Newton linear solver: "gpu" = device multifrontal Cholesky (default), "host" = host Cholesky, "pcg" = conjugate
+        gradients preconditioned by a V-cycle over the AMG levels with H applied matrix-free."""
+        if solver not in self.SOLVERS:
+            raise ValueError("solver must be 'gpu', 'host' or 'pcg'")
+        call("mgb_amg_set_solver", self.handle, self.SOLVERS[solver])
+
+    def set_pcg(self, rtol=0.0, maxit=0, degree=0, power_its=0, lo_frac=0.0, hi_frac=0.0, chunk=0, fallback=None,
+                assembled_top=None):
+        """Parameters of solver="pcg" (unset ones keep their value): see mgb_amg_set_pcg."""
+        flag = lambda v: -1 if v is None else int(bool(v))
+        call("mgb_amg_set_pcg", self.handle, float(rtol), int(maxit), int(degree), int(power_its), float(lo_frac),
+             float(hi_frac), int(chunk), flag(fallback), flag(assembled_top))
+
+    # ---- multigrid pieces (SURVEY.md section 8 a11): mgb_hessian_apply / mgb_smooth / mgb_prolong / mgb_restrict
+    def hessian_apply(self, l, s, v, matrix_free=True):
+        """H(s) v at level l: matrix-free B' (Y o (B v)) on the device, or through the assembled matrix."""
+        s, v = f64(s), f64(v)
+        out = np.empty_like(v)
+        call("mgb_hessian_apply", self.handle, l, dptr(s), dptr(v), dptr(out), int(bool(matrix_free)))
+        return out
+
+    def smooth(self, l, s, b, x0=None, degree=2, sweeps=1, lmax=0.0, matrix_free=True):
+        """Chebyshev-Jacobi smoothing of H(s) x = b from x0 (zero by default); returns (x, lambda_max used)."""
+        s, b = f64(s), f64(b)
+        x = np.zeros_like(b) if x0 is None else f64(x0).copy()
+        used = C.c_double()
+        call("mgb_smooth", self.handle, l, dptr(s), dptr(b), dptr(x), int(degree), int(sweeps), float(lmax),
+             int(bool(matrix_free)), C.byref(used))
+        return x, used.value
+
+    def prolong(self, l, xc):
+        xc = f64(xc)
+        xf = np.empty(self.level_size(l + 1)[0])
+        call("mgb_prolong", self.handle, l, dptr(xc), dptr(xf))
+        return xf
+
+    def restrict(self, l, rf):
+        rf = f64(rf)
+        rc = np.empty(self.level_size(l)[0])
+        call("mgb_restrict", self.handle, l, dptr(rf), dptr(rc))
+        return rc
+
+    def prolongation(self, l) -> sp.csr_matrix:
+        """P_l (N_{l+1} x N_l) with R_l = R_{l+1} P_l."""
+        r, c, nz = C.c_int(), C.c_int(), C.c_int()
+        call("mgb_amg_prolongation", self.handle, l, C.byref(r), C.byref(c), C.byref(nz), None, None, None)
+        rp, ci, va = np.empty(r.value + 1, dtype=np.int32), np.empty(nz.value, dtype=np.int32), np.empty(nz.value)
+        call("mgb_amg_prolongation", self.handle, l, None, None, None, iptr(rp), iptr(ci), dptr(va))
+        return sp.csr_matrix((va, ci, rp), shape=(r.value, c.value))
+
+    def pcg_solve_linear(self, l, s, g):
+        """x = H(s)^{-1} g by V-cycle-preconditioned CG; returns (x, iterations, relative residual in the M norm, converged)."""
+        s, g = f64(s), f64(g)
+        x = np.empty_like(g)
+        it, ok, rr = C.c_int(), C.c_int(), C.c_double()
+        call("mgb_amg_pcg_solve_linear", self.handle, l, dptr(s), dptr(g), dptr(x), C.byref(it), C.byref(rr), C.byref(ok))
+        return x, it.value, rr.value, bool(ok.value)
+
+    def mg_coarsest(self, top=None):
+        c0 = C.c_int()
+        call("mgb_amg_mg_info", self.handle, self.L - 1 if top is None else int(top), C.byref(c0))
+        return c0.value
+
     def solve(self, tol=None, t=0.1, kappa=10.0, maxit=10000, max_newton=0, verbose=0, schedule="fine",
               solver="gpu"):
         if schedule not in ("fine", "all"):
             raise ValueError("schedule must be 'fine' or 'all'")
-        if solver not in ("gpu", "host"):
-            raise ValueError("solver must be 'gpu' or 'host'")
         call("mgb_amg_set_schedule", self.handle, 1 if schedule == "all" else 0)
-        call("mgb_amg_set_solver", self.handle, 1 if solver == "host" else 0)
+        self.set_solver(solver)
         call("mgb_amg_solve", self.handle, float(tol or 0.0), float(t), float(kappa), int(maxit), int(max_newton),
              int(verbose))
         nt, te, tf = C.c_int(), C.c_double(), C.c_double()
@@ -962,9 +1026,12 @@ class AMG:
         call("mgb_amg_sol_kernels", self.handle, dptr(kms), dptr(kby), kl.ctypes.data_as(_lib.c_ll_p))
         kernels = {k: dict(ms=float(m), bytes=float(b), launches=int(c))
                    for k, m, b, c in zip(self.KERNEL_NAMES, kms, kby, kl)}
+        pc = (C.c_longlong * 3)()
+        tp = C.c_double()
+        call("mgb_amg_sol_pcg", self.handle, pc, C.byref(tp))
         return dict(t_elapsed=te.value, ts=ts, its=its.reshape(nt.value, self.L).T.copy(), c_dot_Dz=cd,
                     time_factor=tf.value, n_f0=counts[0], n_f1=counts[1], n_f2=counts[2], n_factor=counts[3],
-                    kernels=kernels)
+                    kernels=kernels, pcg=dict(solves=pc[0], iterations=pc[1], fallbacks=pc[2], seconds=tp.value))
 
     KERNEL_NAMES = ("apply_D", "barrier_f2", "hessian_assemble", "barrier_f1", "restrict", "barrier_f0",
                     "chol_front_start", "chol_front_step", "chol_backward_rect", "chol_backward", "chol_front_single")
@@ -1033,6 +1100,7 @@ def _phase1_slack(geometry, M: "AMG", p, z0, c, tol, schedule, solver):
     M1.set_c(c1)
     M1.set_z(np.column_stack([z0, np.full(n, sigma0)]).reshape(-1, order="F"))
     call("mgb_amg_set_early_stop", M1.handle, K)
+    M1.set_solver(solver)
     M1.prepare()
     SOL = M1.solve(tol=tol, schedule=schedule, solver=solver)
     z1 = M1.get_z().reshape((n, S + 1), order="F")
@@ -1089,6 +1157,9 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
                 raise MGBError(-3, "amgb: feasibility phase failed")
             SOL_feasibility = dict(shift=sigma, its=np.zeros((M.L, 0), dtype=np.int64), ts=np.zeros(0),
                                    c_dot_Dz=np.zeros(0), t_elapsed=0.0)
+    M.set_solver(solver)
+    if rest.get("pcg"):
+        M.set_pcg(**rest["pcg"])      # parameters of solver="pcg", see AMG.set_pcg
     M.prepare()       # factorisation structures are setup, not solve time (SOL_main.t_elapsed mirrors the reference's)
     SOL = M.solve(tol=tol, t=t, kappa=kappa, maxit=maxit, verbose=2 if verbose and verbose > 1 else int(bool(verbose)),
                   schedule=schedule, solver=solver)

@@ -103,6 +103,16 @@ PROTOTYPES = {
     "mgb_amg_solve_linear_gpu": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],
     "mgb_amg_set_solver": [H, C.c_int],
     "mgb_amg_set_schedule": [H, C.c_int],
+    "mgb_amg_set_pcg": [H, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int],
+    "mgb_amg_sol_pcg": [H, c_ll_p, c_dbl_p],
+    "mgb_hessian_apply": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, C.c_int],
+    "mgb_smooth": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, C.c_int, C.c_int, C.c_double, C.c_int, c_dbl_p],
+    "mgb_prolong": [H, C.c_int, c_dbl_p, c_dbl_p],
+    "mgb_restrict": [H, C.c_int, c_dbl_p, c_dbl_p],
+    "mgb_amg_prolongation": [H, C.c_int, c_int_p, c_int_p, c_int_p, c_i32_p, c_i32_p, c_dbl_p],
+    "mgb_amg_pcg_solve_linear": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_int_p, c_dbl_p, c_int_p],
+    "mgb_amg_mg_info": [H, C.c_int, c_int_p],
+    "mgb_plan_prolongation": [H, H, c_int_p, c_int_p, c_int_p, c_i32_p, c_i32_p, c_dbl_p],
     "mgb_amg_solve": [H, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int],
     "mgb_amg_sol_info": [H, c_int_p, c_dbl_p, c_dbl_p, c_ll_p],
     "mgb_amg_sol_get": [H, c_ll_p, c_dbl_p, c_dbl_p],

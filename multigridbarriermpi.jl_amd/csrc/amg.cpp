@@ -474,6 +474,12 @@ size_t reduction_scratch_doubles(int n_local, int max_level_unknowns) {
   return (size_t)6 * std::max(f0_blocks(n_local), f0_blocks(max_level_unknowns)) + 8 + kReductionHeader;      // three trial points x two sums per block, incl. the ticket words
 }
 
+int Amg::level_index(const Level& lv) const {
+  for (size_t l = 0; l < levels_.size(); ++l)
+    if (levels_[l].get() == &lv) return (int)l;
+  throw InternalError("amg: level not found");
+}
+
 Amg::Level& Amg::level(int l) {
   Level& lv = *levels_.at(l);
   if (lv.built) return lv;
@@ -542,7 +548,9 @@ void Amg::prepare(int l) {
   const int L = (int)levels_.size();
   for (int J = (l >= 0 ? l : (schedule_all_ ? 0 : L - 1)); J <= (l >= 0 ? l : L - 1); ++J) {
     Level& lv = level(J);
-    if (lv.plan.N > 0) ensure_chol(lv);
+    if (lv.plan.N == 0) continue;
+    if (pcg_) mg_prepare(J);
+    else ensure_chol(lv);
   }
 }
 
@@ -721,6 +729,11 @@ void Amg::enqueue_f2_assemble(Level& lv, const double* dz, SolveStats& st) {
   timer_.begin(ctx_.stream, KC_F2, (double)n_ * (P_.K + 1 + P_.nY()) * 8);
   launch_barrier_f2(ctx_.stream, n_, P_, dz, w_.p, Y_.p);
   timer_.end(ctx_.stream);
+  if (pcg_) {      // no assembled top-level matrix: Y is the operator; the hierarchy below it gets its values and estimates
+    mg_values(level_index(lv));
+    st.n_f2++;
+    return;
+  }
   timer_.begin(ctx_.stream, KC_ASSEMBLE, csr_bytes(lv.T.view, false));
   launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
   timer_.end(ctx_.stream);
@@ -748,7 +761,7 @@ double Amg::dev_f1(Level& lv, const double* dz, double t, double* g_out, SolveSt
     hip_check(hipMemcpyAsync(lv.h_g.p, g_out, (size_t)lv.plan.N * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream),
               "D2H g");
   if (pre && st && !host_solve_) {
-    ensure_chol(lv);
+    if (!pcg_) ensure_chol(lv);
     if (ctx_.world > 1) {      // single GPU: the dot kernel's completion signal is what the host waits for -- no event packet
       if (!ev_f1_) hip_check(hipEventCreateWithFlags(&ev_f1_, hipEventDisableTiming), "event");      // (the packet cost ~10 us per step)
       hip_check(hipEventRecord(ev_f1_, ctx_.stream), "record f1");
@@ -840,11 +853,42 @@ void Amg::launch_step_graph(Level& lv, Trial* spec) {
 bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, double* inc, Trial* spec,
                        const double* pre_assembled) {
   const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
-  ensure_chol(lv);
+  if (!pcg_) ensure_chol(lv);
   if (pre_assembled != dz) enqueue_f2_assemble(lv, dz, st);      // else: done behind the gradient of this point
   st.n_factor++;
   // event pairs cost ~14 % of a solve when every launch is bracketed: time every 8th Newton step only
   timer_.sample((st.n_factor % 8) == 1);
+  if (pcg_) {
+    // V-cycle-preconditioned CG on H n = g, H applied matrix-free (amg_mg.cpp); then <g, n> and the speculated trial points
+    // exactly as behind the direct solver.  A CG that stops without converging hands the step to the device Cholesky.
+    const int top = level_index(lv);
+    bool ok = pcg_run(lv, top, lv.g.p, lv.nstep.p, &st, nullptr, nullptr);
+    h_flag_.p[0] = 0;
+    if (!ok) {
+      if (!pcg_opt.fallback) return false;
+      st.pcg_fallbacks++;
+      ensure_chol(lv);
+      launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
+      lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g.p, lv.nstep.p, nullptr, false);
+      lv.flag_armed = false;
+      hip_check(hipMemcpyAsync(h_flag_.p, lv.gchol.fail_flag(), sizeof(int), hipMemcpyDeviceToHost, ctx_.stream), "D2H flag");
+    }
+    launch_dot(ctx_.stream, N, lv.g.p, lv.nstep.p, partials_.p, scal_.p + 3, host_scal(scal_.p + 3), nullptr, nullptr,
+               spec ? HostSignal() : next_signal());
+    if (spec) {
+      enqueue_spec_trials(lv, spec, next_signal());
+      st.n_f0 += spec_count();
+    }
+    wait_signal("sync pcg solve");
+    if (!ok) hip_check(hipStreamSynchronize(ctx_.stream), "sync fallback flag");
+    if (spec)
+      for (int q = 0; q < spec_count(); ++q) {
+        spec[q].y = h_scal_.p[4 + 2 * q] + t * h_scal_.p[5 + 2 * q];
+        spec[q].valid = true;
+      }
+    *inc = h_scal_.p[3];
+    return h_flag_.p[0] == 0;
+  }
   if (!host_solve_) {
     // device multifrontal factorisation + sweeps: nothing but a few scalars and a flag cross PCIe.  Three launch modes:
     //   sampled steps (every 8th, when timing is on): plain launches bracketed by HIP events (KernelTimer);
@@ -1148,6 +1192,14 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   const size_t zbytes = (size_t)n_ * S_ * sizeof(double), dzbytes = (size_t)n_ * P_.K * sizeof(double);
   schedule_all_ = opt.schedule_all;
   host_solve_ = opt.host_solve;
+  pcg_ = opt.pcg && !opt.host_solve;
+  if (pcg_ && ctx_.world > 1) throw ArgError("amgb: solver pcg runs on single-GPU contexts (sharded contexts use the direct solver)");
+  if (pcg_)
+    for (int J = (schedule_all_ ? 0 : L - 1); J < L; ++J)
+      if (level(J).plan.N > 0) mg_prepare(J);
+  //  a launch that threw after its signal was counted must not leave the host counter ahead of the device's
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync before solve");
+  seq_expected_ = *h_seq_.p;
   std::vector<long long> its(L, 0);
   refresh_dz0();
   {

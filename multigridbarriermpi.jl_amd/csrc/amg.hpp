@@ -22,6 +22,7 @@
 #include "gpuchol.hpp"
 #include "kernels.hpp"
 #include "mfchol.hpp"
+#include "mg.hpp"
 
 namespace mgb {
 
@@ -109,6 +110,37 @@ struct DevElCsrOwned {
   bool build(const Csr& A, int rows_per_el);
 };
 
+// Owning element-operator view of B = D R_l for the matrix-free Hessian product (mg.hpp: DevElOp): structure classes, the dof
+// gather lists; B's rowptr / values stay the level's own device CSR.  Invalid when the rows do not come in element blocks.
+struct DevElOpOwned {
+  DevElOp view;
+  DevBuf<int> ecols, cls, dptr, didx;
+  DevBuf<unsigned short> c_rowptr, c_tptr, c_tk, c_trow;
+  DevBuf<unsigned char> c_lcol;
+  // block = nodes per element, K = rows of D: rows [e block K, (e + 1) block K) of B form element e
+  bool build(const Csr& B, const DevCsr& Bdev, int block, int K);
+};
+
+// Host-side symbolic pieces of the multigrid hierarchy (testable without a GPU)
+// P with Rf P = Rc: the level-l basis expressed in the unknowns of level l + 1 (both given on the finest broken nodes); rows of
+// P are read off the finest-mesh nodes that carry a single level-(l+1) unknown with weight one (nodal hierarchies)
+Csr build_prolongation(const Csr& Rf, const Csr& Rc);
+// full symmetric CSR pattern of a lower-triangle pattern; map[k] = index of full entry k in the lower values, diagpos[i] =
+// position of (i, i) in the full pattern
+Csr sym_full_pattern(const Csr& lower, std::vector<int>& map, std::vector<int>& diagpos);
+
+// V-cycle-preconditioned CG as the Newton linear solver (solver = "pcg")
+struct PcgOptions {
+  double rtol = 1e-9;      // on sqrt(<r, M r> / <r0, M r0>)
+  int maxit = 200;
+  int degree = 2;          // operator applications per Chebyshev pre- / post-smoothing
+  int power_its = 6;       // power steps per level and Newton matrix for lambda_max(Dinv A) (warm-started)
+  double lo_frac = 0.1, hi_frac = 1.1;      // Chebyshev interval as fractions of the estimate
+  int chunk = 4;           // CG iterations enqueued between two looks at the convergence flag
+  bool fallback = true;    // direct solve of the step when CG stops without converging
+  bool assembled_top = false;      // finest level through its assembled matrix instead of the matrix-free product (A/B runs)
+};
+
 struct AmgSpec {
   std::vector<std::pair<std::string, std::string>> state_variables;  // (name, subspace key)
   std::vector<std::pair<std::string, std::string>> D;                // (state var, operator key)
@@ -157,6 +189,7 @@ constexpr int kInitialCenteringAttempts = 8;   // == oracle INITIAL_CENTERING_AT
 
 struct SolveOptions {
   bool host_solve = false;              // true: factor/solve on the host (MfChol), false: on the GPU (GpuChol)
+  bool pcg = false;                     // true: V-cycle-preconditioned CG on the GPU (PcgOptions of the Amg)
   bool schedule_all = false;            // false: finest level only; true: coarse -> fine level loop
   bool time_kernels = true;             // bracket kernels with HIP events (a few us of host time per step)
   double tol = 1.4901161193847656e-08;  // sqrt(eps)
@@ -174,6 +207,8 @@ struct SolveStats {
   double t_elapsed = 0, t_setup = 0;
   double time_factor = 0, time_device = 0;
   long long n_factor = 0, n_f0 = 0, n_f1 = 0, n_f2 = 0;
+  long long pcg_solves = 0, pcg_iters = 0, pcg_fallbacks = 0;      // solver = pcg: Newton systems, CG iterations, direct fallbacks
+  double time_pcg = 0;
   // live HIP-event timing of the six kernel classes over the solve (KernelClass order)
   double kern_ms[KC_COUNT] = {};
   double kern_bytes[KC_COUNT] = {};
@@ -223,6 +258,8 @@ class Amg {
   // feasibility phases: stop the continuation after the first centering at which row `col` of Dz is negative at every node
   // (col < 0: off).  The solve then returns normally with fewer t-steps instead of running to t_stop.
   void set_early_stop(int col) { early_stop_col_ = col; }
+  // solver = pcg for prepare() and the fine-grained entry points between solves (solve() takes it from its options)
+  void set_pcg(bool on) { pcg_ = on; }
 
   // problem data: c is n x K row-major, z is the S*n vector [u; s]
   void set_c(const double* c_host);
@@ -282,12 +319,25 @@ class Amg {
     GpuChol gchol;    // device numeric factorisation / sweeps on the same tree
     DevBuf<double> s, s_trial, s_trial2, s_trial3, g, g_trial, nstep, avals;
     PinnedBuf<double> h_avals, h_g, h_n, h_s;
+    // multigrid data of the level (amg_mg.cpp), built on first use
+    struct Mg {
+      bool elop_tried = false, assembled = false, transfer = false, vectors = false;
+      DevElOpOwned elop;              // matrix-free operator B' Y B
+      DevBuf<double> elbuf;
+      DevCsrOwned A;                  // assembled operator, full symmetric storage (values rewritten per Newton matrix)
+      DevBuf<int> amap, diagpos, lo_rowptr, lo_colidx;
+      DevCsrOwned P, PT;              // prolongation to level l + 1 (N_{l+1} x N_l) and its transpose
+      DevBuf<double> dinv, x, b, r, d0, d1, ev0, ev1, coef, Ainv;
+      double lmax_host = 0;
+    };
+    std::unique_ptr<Mg> mg;
   };
   struct NewtonResult {
     int k = 0;
     bool converged = false;
   };
   Level& level(int l);            // lazily built
+  int level_index(const Level& lv) const;
   void ensure_chol(Level& lv);    // factorisation structures, built on first solve
   void refresh_dz0();
   void dev_apply(Level& lv, const double* s_dev, double* dz);     // dz = Dz0 + B s
@@ -336,6 +386,46 @@ class Amg {
   NewtonResult newton(int l, double t, bool finest, double lam_tol, int maxit, SolveStats& st, int verbose);
   bool amgb_step(double t, double lam_tol, int max_newton, std::vector<long long>& its, SolveStats& st, int verbose);
   double c_dot_dz();
+
+  // ---- multigrid / CG (amg_mg.cpp)
+ public:
+  PcgOptions pcg_opt;
+  // H v at the point s of level l: matrix-free (B' (Y o (B v)), element-local) or through the assembled matrix
+  void hessian_apply(int l, const double* s_host, const double* v_host, double* out_host, bool matrix_free);
+  // `sweeps` Chebyshev-Jacobi smoothing passes of `degree` operator applications each on H(s) x = b at level l from the
+  // given x (in / out); lmax > 0: use it as lambda_max(Dinv H), else estimate on the device; returns the value used
+  double mg_smooth(int l, const double* s_host, const double* b_host, double* x_host, int degree, int sweeps, double lmax,
+                   bool matrix_free);
+  void mg_prolong(int l, const double* xc_host, double* xf_host);      // level l -> l + 1
+  void mg_restrict(int l, const double* rf_host, double* rc_host);     // level l + 1 -> l
+  int mg_coarsest(int top);      // coarsest level of the V-cycle below `top`
+  // x = H(s)^{-1} g by V-cycle-preconditioned CG at level l; returns false if it stopped without converging
+  bool pcg_solve_linear(int l, const double* s_host, const double* g_host, double* x_host, int* iters, double* relres);
+  const Csr& prolongation_host(int l);      // P_l as built on the host (tests)
+
+ private:
+  Level::Mg& mg_of(Level& lv);
+  void mg_ensure_vectors(Level& lv);
+  bool mg_ensure_elop(Level& lv);
+  void mg_ensure_assembled(Level& lv);
+  void mg_ensure_transfer(int l);           // P_l, P_l' on level l (to level l + 1)
+  void mg_prepare(int top);                 // everything the V-cycle below `top` needs (host + upload)
+  bool mg_top_matrix_free(int top);
+  void mg_values(int top);                  // numeric setup for the Hessian whose Y is in Y_: operators, diagonals, eigenvalue estimates
+  void mg_level_values(Level& lv, bool mf);
+  void mg_estimate(Level& lv, bool mf, double lmax_given);
+  void mg_apply(Level& lv, bool mf, const MgEpi& epi);
+  void mg_smooth_pre(Level& lv, bool mf, const double* b, double* x, double* r, int degree, const double* done);
+  void mg_smooth_post(Level& lv, bool mf, const double* b, double* x, double* r, int degree, const double* done);
+  void mg_vcycle(int top, int l, const double* b, double* x, const double* done);
+  bool pcg_run(Level& lv, int top, const double* g, double* x, SolveStats* st, int* iters, double* relres);
+  void eval_Y_at(Level& lv, const double* s_host);
+  std::vector<Csr> P_host_;
+  DevBuf<double> mg_scal_, mg_scratch_, pcg_r_, pcg_z_, pcg_p_, pcg_Ap_;
+  PinnedBuf<double> h_pcg_;
+  DevBuf<int> mg_fail_;
+  bool mg_inited_ = false;
+  bool pcg_ = false;
 
   Ctx& ctx_;
   int n_ = 0, S_ = 0;

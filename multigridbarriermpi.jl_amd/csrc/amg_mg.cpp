@@ -1,0 +1,622 @@
+// Multigrid hierarchy, V-cycle and preconditioned CG of the Newton path (kernels: mg.hip).
+//
+// Hierarchy: the reference's AMG levels R_l = blockdiag(subspaces[sv][l]) (test/test_d0_construction.jl:82-100) are nested,
+// R_l = R_{l+1} P_l, so the Newton matrices A_l = R_l' H R_l (test/test_map_rows_compare.jl:102-123,165-170) are the Galerkin
+// operators P_l' A_{l+1} P_l of one another.  A V-cycle over them -- Chebyshev-Jacobi smoothing, dense inverse on the coarsest
+// level -- preconditions CG on the Newton system of the top level, whose operator is applied matrix-free:
+// H v = B' (Y o (B v)).  The reference solves the same system directly (MultiGridBarrier.solve -> MUMPS,
+// test/test_instrumented_solve.jl:25-28,99): solver = "pcg" is an alternative to the device Cholesky, not a change of algorithm.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+
+#include "amg.hpp"
+
+namespace mgb {
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------ host symbolic pieces
+
+bool DevElOpOwned::build(const Csr& B, const DevCsr& Bdev, int block, int K) {
+  view = DevElOp();
+  const int rpe = block * K;
+  if (block < 1 || K < 1 || K > 8 || rpe > 65535 || B.rows == 0 || B.rows % rpe) return false;
+  const int nel = B.rows / rpe;
+  std::vector<std::vector<int>> cols(nel);
+  int cmax = 0, nzm = 0;
+  for (int e = 0; e < nel; ++e) {
+    std::vector<int>& c = cols[e];
+    c.assign(B.colidx.begin() + B.rowptr[e * rpe], B.colidx.begin() + B.rowptr[(e + 1) * rpe]);
+    nzm = std::max(nzm, (int)c.size());
+    std::sort(c.begin(), c.end());
+    c.erase(std::unique(c.begin(), c.end()), c.end());
+    cmax = std::max(cmax, (int)c.size());
+  }
+  if (cmax < 1 || cmax > 255 || nzm > 65535) return false;
+  // elements per workgroup pass: ~512 rows, staging buffers within 60 KiB of LDS
+  int epb = std::max(1, std::min(64, 512 / rpe));
+  while (epb > 1 && (size_t)epb * (cmax + nzm + rpe) * 8 > 60 * 1024) --epb;
+  if ((size_t)epb * (cmax + nzm + rpe) * 8 > 60 * 1024) return false;
+  // structure classes: (relative row offsets, local columns) -> class id
+  std::map<std::string, int> ids;
+  std::vector<int> cls(nel);
+  std::vector<unsigned short> c_rowptr, c_tptr, c_tk, c_trow;
+  std::vector<unsigned char> c_lcol;
+  std::vector<int> ec((size_t)nel * cmax);
+  std::string key;
+  std::vector<unsigned char> lc;
+  for (int e = 0; e < nel; ++e) {
+    const std::vector<int>& c = cols[e];
+    for (int j = 0; j < cmax; ++j) ec[(size_t)e * cmax + j] = j < (int)c.size() ? c[j] : c[0];
+    const int k0 = B.rowptr[e * rpe], k1 = B.rowptr[(e + 1) * rpe];
+    lc.resize(k1 - k0);
+    for (int k = k0; k < k1; ++k) lc[k - k0] = (unsigned char)(std::lower_bound(c.begin(), c.end(), B.colidx[k]) - c.begin());
+    key.assign((const char*)lc.data(), lc.size());
+    for (int r = 0; r <= rpe; ++r) {
+      const unsigned short off = (unsigned short)(B.rowptr[e * rpe + r] - k0);
+      key.append((const char*)&off, sizeof off);
+    }
+    auto it = ids.find(key);
+    if (it == ids.end()) {
+      const int id = (int)ids.size();
+      it = ids.emplace(key, id).first;
+      c_rowptr.resize((size_t)(id + 1) * (rpe + 1));
+      c_lcol.resize((size_t)(id + 1) * nzm, 0);
+      c_tptr.resize((size_t)(id + 1) * (cmax + 1));
+      c_tk.resize((size_t)(id + 1) * nzm, 0);
+      c_trow.resize((size_t)(id + 1) * nzm, 0);
+      for (int r = 0; r <= rpe; ++r) c_rowptr[(size_t)id * (rpe + 1) + r] = (unsigned short)(B.rowptr[e * rpe + r] - k0);
+      std::copy(lc.begin(), lc.end(), c_lcol.begin() + (size_t)id * nzm);
+      // column-wise traversal: rows ascending within a column (a node's K rows are consecutive)
+      std::vector<int> cnt(cmax + 1, 0);
+      for (unsigned char j : lc) cnt[j + 1]++;
+      for (int j = 0; j < cmax; ++j) cnt[j + 1] += cnt[j];
+      for (int j = 0; j <= cmax; ++j) c_tptr[(size_t)id * (cmax + 1) + j] = (unsigned short)cnt[j];
+      std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+      for (int r = 0; r < rpe; ++r)
+        for (int k = B.rowptr[e * rpe + r] - k0; k < B.rowptr[e * rpe + r + 1] - k0; ++k) {
+          const int pp = pos[lc[k]]++;
+          c_tk[(size_t)id * nzm + pp] = (unsigned short)k;
+          c_trow[(size_t)id * nzm + pp] = (unsigned short)r;
+        }
+    }
+    cls[e] = it->second;
+  }
+  // dof gather lists: slots (e, j) of real columns only, elements ascending
+  const int N = B.cols;
+  std::vector<int> dptr(N + 1, 0), didx;
+  for (int e = 0; e < nel; ++e)
+    for (int c : cols[e]) dptr[c + 1]++;
+  for (int i = 0; i < N; ++i) dptr[i + 1] += dptr[i];
+  didx.resize(dptr[N]);
+  {
+    std::vector<int> pos(dptr.begin(), dptr.end() - 1);
+    for (int e = 0; e < nel; ++e)
+      for (int j = 0; j < (int)cols[e].size(); ++j) didx[pos[cols[e][j]]++] = e * cmax + j;
+  }
+  this->ecols.upload(ec.data(), ec.size());
+  this->cls.upload(cls.data(), cls.size());
+  this->dptr.upload(dptr.data(), dptr.size());
+  this->didx.upload(didx.data(), didx.size());
+  this->c_rowptr.upload(c_rowptr.data(), c_rowptr.size());
+  this->c_lcol.upload(c_lcol.data(), c_lcol.size());
+  this->c_tptr.upload(c_tptr.data(), c_tptr.size());
+  this->c_tk.upload(c_tk.data(), c_tk.size());
+  this->c_trow.upload(c_trow.data(), c_trow.size());
+  view.nel = nel;
+  view.rows_per_el = rpe;
+  view.cmax = cmax;
+  view.K = K;
+  view.block = block;
+  view.nnz_max = nzm;
+  view.ncls = (int)ids.size();
+  view.N = N;
+  view.epb = epb;
+  view.ecols = this->ecols.p;
+  view.cls = this->cls.p;
+  view.rowptr = Bdev.rowptr;
+  view.vals = Bdev.vals;
+  view.c_rowptr = this->c_rowptr.p;
+  view.c_lcol = this->c_lcol.p;
+  view.c_tptr = this->c_tptr.p;
+  view.c_tk = this->c_tk.p;
+  view.c_trow = this->c_trow.p;
+  view.dptr = this->dptr.p;
+  view.didx = this->didx.p;
+  return true;
+}
+
+Csr build_prolongation(const Csr& Rf, const Csr& Rc) {
+  if (Rf.rows != Rc.rows) throw ArgError("mg: levels live on different node sets");
+  const int Nf = Rf.cols;
+  std::vector<int> rep(Nf, -1);
+  for (int r = 0; r < Rf.rows; ++r) {
+    int col = -1, big = 0;
+    for (int k = Rf.rowptr[r]; k < Rf.rowptr[r + 1]; ++k)
+      if (std::fabs(Rf.vals[k]) > 1e-12) {
+        ++big;
+        col = std::fabs(Rf.vals[k] - 1.0) < 1e-12 ? Rf.colidx[k] : -1;
+      }
+    if (big == 1 && col >= 0 && rep[col] < 0) rep[col] = r;
+  }
+  for (int i = 0; i < Nf; ++i)
+    if (rep[i] < 0)
+      throw ArgError("mg: the level hierarchy is not nodal (no node of the finest mesh carries unknown " + std::to_string(i) +
+                     " of a level alone): the V-cycle needs nested nodal subspaces");
+  Csr P(Nf, Rc.cols);
+  for (int i = 0; i < Nf; ++i) {
+    const int r = rep[i];
+    for (int k = Rc.rowptr[r]; k < Rc.rowptr[r + 1]; ++k)
+      if (std::fabs(Rc.vals[k]) > 1e-14) {
+        P.colidx.push_back(Rc.colidx[k]);
+        P.vals.push_back(Rc.vals[k]);
+      }
+    P.rowptr[i + 1] = (int)P.colidx.size();
+  }
+  return P;
+}
+
+Csr sym_full_pattern(const Csr& lower, std::vector<int>& map, std::vector<int>& diagpos) {
+  const int N = lower.rows;
+  Csr F(N, N);
+  std::vector<int> cnt(N, 0);
+  for (int i = 0; i < N; ++i)
+    for (int k = lower.rowptr[i]; k < lower.rowptr[i + 1]; ++k) {
+      const int j = lower.colidx[k];
+      if (j > i) throw ArgError("mg: pattern is not lower triangular");
+      cnt[i]++;
+      if (j != i) cnt[j]++;
+    }
+  for (int i = 0; i < N; ++i) F.rowptr[i + 1] = F.rowptr[i] + cnt[i];
+  F.colidx.assign(F.rowptr[N], 0);
+  F.vals.assign(F.rowptr[N], 0.0);
+  map.assign(F.rowptr[N], 0);
+  diagpos.assign(N, -1);
+  std::vector<int> pos(F.rowptr.begin(), F.rowptr.end() - 1);
+  // row i: its lower entries (columns ascending, incl. the diagonal) come first when rows are visited in order, and the
+  // transposed entries (i, i') of later rows i' > i are appended in ascending i' -- every row ends up sorted
+  for (int i = 0; i < N; ++i)
+    for (int k = lower.rowptr[i]; k < lower.rowptr[i + 1]; ++k) {
+      const int j = lower.colidx[k];
+      const int pi = pos[i]++;
+      F.colidx[pi] = j;
+      map[pi] = k;
+      if (j == i) diagpos[i] = pi;
+    }
+  for (int i = 0; i < N; ++i)
+    for (int k = lower.rowptr[i]; k < lower.rowptr[i + 1]; ++k) {
+      const int j = lower.colidx[k];
+      if (j == i) continue;
+      const int pj = pos[j]++;
+      F.colidx[pj] = i;
+      map[pj] = k;
+    }
+  for (int i = 0; i < N; ++i)
+    if (diagpos[i] < 0) throw ArgError("mg: Hessian pattern without a diagonal entry");
+  return F;
+}
+
+// ------------------------------------------------------------------ per-level data
+
+Amg::Level::Mg& Amg::mg_of(Level& lv) {
+  if (!lv.mg) lv.mg.reset(new Level::Mg);
+  if (!mg_inited_) {
+    hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
+    mg_device_init();
+    mg_scal_.alloc(SC_COUNT);
+    hip_check(hipMemset(mg_scal_.p, 0, SC_COUNT * sizeof(double)), "memset mg scalars");
+    mg_scratch_.alloc(kReductionHeader + 4096);
+    hip_check(hipMemset(mg_scratch_.p, 0, mg_scratch_.n * sizeof(double)), "memset mg scratch");
+    h_pcg_.alloc(4);
+    mg_fail_.alloc(1);
+    hip_check(hipMemset(mg_fail_.p, 0, sizeof(int)), "memset mg flag");
+    mg_inited_ = true;
+  }
+  return *lv.mg;
+}
+
+void Amg::mg_ensure_vectors(Level& lv) {
+  Level::Mg& m = mg_of(lv);
+  if (m.vectors) return;
+  const int N = lv.plan.N;
+  m.dinv.alloc(N);
+  m.x.alloc(N);
+  m.b.alloc(N);
+  m.r.alloc(N);
+  m.d0.alloc(N);
+  m.d1.alloc(N);
+  m.ev0.alloc(N);
+  m.ev1.alloc(N);
+  m.coef.alloc(kChebStride);
+  // deterministic start vector of the power iteration (warm-started from the last estimate afterwards)
+  std::vector<double> ev(N);
+  unsigned long long sd = 0x9e3779b97f4a7c15ull;
+  for (int i = 0; i < N; ++i) {
+    sd = sd * 6364136223846793005ull + 1442695040888963407ull;
+    ev[i] = 0.5 + (double)(sd >> 11) * (1.0 / 9007199254740992.0);
+  }
+  m.ev0.upload(ev.data(), N);
+  m.vectors = true;
+}
+
+bool Amg::mg_ensure_elop(Level& lv) {
+  Level::Mg& m = mg_of(lv);
+  if (!m.elop_tried) {
+    m.elop_tried = true;
+    if (geo_.block >= 1 && n_ % geo_.block == 0 && m.elop.build(lv.plan.B, lv.B.view, geo_.block, P_.K))
+      m.elbuf.alloc((size_t)m.elop.view.nel * m.elop.view.cmax);
+  }
+  return m.elop.view.valid();
+}
+
+void Amg::mg_ensure_assembled(Level& lv) {
+  Level::Mg& m = mg_of(lv);
+  if (m.assembled) return;
+  std::vector<int> map, diagpos;
+  Csr F = sym_full_pattern(lv.plan.Apat, map, diagpos);
+  m.A.upload(F);
+  m.amap.upload(map.data(), map.size());
+  m.diagpos.upload(diagpos.data(), diagpos.size());
+  m.lo_rowptr.upload(lv.plan.Apat.rowptr.data(), lv.plan.Apat.rowptr.size());
+  m.lo_colidx.upload(lv.plan.Apat.colidx.data(), lv.plan.Apat.colidx.size());
+  m.assembled = true;
+}
+
+const Csr& Amg::prolongation_host(int l) {
+  mg_ensure_transfer(l);
+  return P_host_.at(l);
+}
+
+void Amg::mg_ensure_transfer(int l) {
+  if (l < 0 || l + 1 >= (int)levels_.size()) throw ArgError("mg: no finer level to prolong to");
+  if (ctx_.world > 1) throw ArgError("mg: the V-cycle runs on single-GPU contexts (sharded contexts use the direct solver)");
+  Level& lc = level(l);
+  Level::Mg& m = mg_of(lc);
+  if (m.transfer) return;
+  Level& lf = level(l + 1);
+  if ((int)P_host_.size() < (int)levels_.size()) P_host_.resize(levels_.size());
+  P_host_[l] = build_prolongation(lf.plan.R, lc.plan.R);
+  m.P.upload(P_host_[l]);
+  m.PT.upload(transpose(P_host_[l]));
+  m.transfer = true;
+}
+
+int Amg::mg_coarsest(int top) {
+  int c0 = 0;
+  for (int l = 0; l <= top; ++l)
+    if (levels_[l]->plan.N > 0 && levels_[l]->plan.N <= kDenseMax) c0 = l;
+  while (c0 < top && levels_[c0]->plan.N == 0) ++c0;
+  return c0;
+}
+
+// the top level applies H matrix-free (unless it is itself the coarsest level, which needs its assembled values for the inverse)
+bool Amg::mg_top_matrix_free(int top) {
+  return !pcg_opt.assembled_top && mg_coarsest(top) != top && mg_ensure_elop(level(top));
+}
+
+void Amg::mg_prepare(int top) {
+  if (ctx_.world > 1) throw ArgError("pcg: single-GPU contexts only (sharded contexts use the direct solver)");
+  hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
+  if (pcg_opt.degree < 1 || pcg_opt.degree > kChebMaxDegree) throw ArgError("pcg: smoothing degree must be 1..7");
+  const int c0 = mg_coarsest(top);
+  for (int l = c0; l <= top; ++l) {
+    Level& lv = level(l);
+    mg_ensure_vectors(lv);
+    if (l < top) mg_ensure_transfer(l);
+    if (l == top && mg_top_matrix_free(top)) continue;
+    mg_ensure_assembled(lv);
+  }
+  Level& lc = level(c0);
+  if (lc.plan.N <= kDenseMax) {
+    if (lc.mg->Ainv.n == 0) lc.mg->Ainv.alloc((size_t)lc.plan.N * lc.plan.N);
+  } else {
+    ensure_chol(lc);      // coarse meshes too large for the dense inverse: the device Cholesky of that level
+  }
+  Level& lt = level(top);
+  if (pcg_r_.n < (size_t)lt.plan.N) {
+    pcg_r_.alloc(lt.plan.N);
+    pcg_z_.alloc(lt.plan.N);
+    pcg_p_.alloc(lt.plan.N);
+    pcg_Ap_.alloc(lt.plan.N);
+  }
+}
+
+// ------------------------------------------------------------------ numeric setup per Newton matrix (Y_ holds w F2(Dz))
+
+void Amg::mg_apply(Level& lv, bool mf, const MgEpi& epi) {
+  if (mf) launch_elop_apply(ctx_.stream, lv.mg->elop.view, P_, Y_.p, lv.mg->elbuf.p, epi);
+  else launch_csr_apply(ctx_.stream, lv.mg->A.view, epi);
+}
+
+void Amg::mg_level_values(Level& lv, bool mf) {
+  Level::Mg& m = *lv.mg;
+  if (mf) {
+    launch_elop_diaginv(ctx_.stream, m.elop.view, P_, Y_.p, m.elbuf.p, m.dinv.p);
+    return;
+  }
+  // assembled: lower-triangle values from the level's Hessian plan (the reference's recipe evaluated on its fixed pattern,
+  // test/test_map_rows_compare.jl:102-123), mirrored into the full symmetric storage the smoother sweeps over
+  launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
+  launch_expand_sym(ctx_.stream, m.A.view.nnz, m.amap.p, lv.avals.p, m.A.vals.p, lv.plan.N, m.diagpos.p, m.dinv.p);
+}
+
+// lambda_max(Dinv A) by power steps in the D inner product (in which Dinv A is self-adjoint: the quotient never exceeds
+// lambda_max and grows monotonically), warm-started; then the level's Chebyshev coefficients.  Entirely on the stream.
+void Amg::mg_estimate(Level& lv, bool mf, double lmax_given) {
+  Level::Mg& m = *lv.mg;
+  const int N = lv.plan.N;
+  if (lmax_given > 0) {      // tests: the same interval rule from an eigenvalue computed elsewhere
+    hip_check(hipStreamSynchronize(ctx_.stream), "sync lmax");
+    hip_check(hipMemcpy(mg_scal_.p + SC_LMAX, &lmax_given, sizeof(double), hipMemcpyHostToDevice), "H2D lmax");
+    launch_cheb_coef(ctx_.stream, mg_scal_.p, m.coef.p, std::max(pcg_opt.degree, 1), pcg_opt.lo_frac, pcg_opt.hi_frac);
+    return;
+  }
+  launch_power_start(ctx_.stream, N, m.ev0.p, m.dinv.p, mg_scal_.p, mg_scratch_.p);
+  for (int it = 0; it < pcg_opt.power_its; ++it) {
+    MgEpi e;
+    e.mode = MG_POWER;
+    e.n = N;
+    e.v = m.ev0.p;
+    e.vscale = mg_scal_.p + SC_VSCALE;
+    e.out = m.ev1.p;
+    e.dinv = m.dinv.p;
+    e.scal = mg_scal_.p;
+    e.scratch = mg_scratch_.p;
+    mg_apply(lv, mf, e);
+    std::swap(m.ev0.p, m.ev1.p);
+  }
+  launch_cheb_coef(ctx_.stream, mg_scal_.p, m.coef.p, std::max(pcg_opt.degree, 1), pcg_opt.lo_frac, pcg_opt.hi_frac);
+}
+
+void Amg::mg_values(int top) {
+  const int c0 = mg_coarsest(top);
+  const bool mf_top = mg_top_matrix_free(top);
+  for (int l = c0; l <= top; ++l) {
+    Level& lv = level(l);
+    if (lv.plan.N == 0) continue;
+    const bool mf = (l == top) && mf_top;
+    mg_level_values(lv, mf);
+    if (l > c0) mg_estimate(lv, mf, 0.0);
+  }
+  Level& lc = level(c0);
+  if (lc.plan.N <= kDenseMax)
+    launch_dense_inverse(ctx_.stream, lc.plan.N, lc.mg->lo_rowptr.p, lc.mg->lo_colidx.p, lc.avals.p, lc.mg->Ainv.p, mg_fail_.p);
+}
+
+// ------------------------------------------------------------------ smoothing / V-cycle (enqueue only)
+
+void Amg::mg_smooth_pre(Level& lv, bool mf, const double* b, double* x, double* r, int degree, const double* done) {
+  Level::Mg& m = *lv.mg;
+  double* D[2] = {m.d0.p, m.d1.p};
+  for (int a = 0; a < degree; ++a) {
+    MgEpi e;
+    e.n = lv.plan.N;
+    e.mode = a == 0 ? MG_FIRST : MG_STEP;
+    e.b = b;
+    e.v = a == 0 ? nullptr : D[(a - 1) & 1];
+    e.x = x;
+    e.r = r;
+    e.dinv = m.dinv.p;
+    e.coef = m.coef.p;
+    e.has_next = a < degree - 1;
+    e.k = a + 1;
+    e.d_new = D[a & 1];
+    e.done = done;
+    mg_apply(lv, mf, e);
+  }
+}
+
+void Amg::mg_smooth_post(Level& lv, bool mf, const double* b, double* x, double* r, int degree, const double* done) {
+  Level::Mg& m = *lv.mg;
+  double* D[2] = {m.d0.p, m.d1.p};
+  for (int a = 0; a < degree; ++a) {
+    MgEpi e;
+    e.n = lv.plan.N;
+    e.mode = a == 0 ? MG_RESID : MG_STEP;
+    e.b = b;
+    e.v = a == 0 ? x : D[(a - 1) & 1];
+    e.x = x;
+    e.r = r;
+    e.dinv = m.dinv.p;
+    e.coef = m.coef.p;
+    e.has_next = 1;
+    e.add_new = a == degree - 1;
+    e.k = a;
+    e.d_new = D[a & 1];
+    e.done = done;
+    mg_apply(lv, mf, e);
+  }
+  if (degree == 1) launch_waxpby(ctx_.stream, lv.plan.N, x, 1.0, D[0], x);      // x += d_0 cannot ride in the launch that gathers x
+}
+
+// x = V(b): one symmetric V-cycle from x = 0 on the levels c0 .. top.  Level vectors: the top level works on the caller's b / x.
+void Amg::mg_vcycle(int top, int l, const double* b, double* x, const double* done) {
+  Level& lv = level(l);
+  Level::Mg& m = *lv.mg;
+  const int c0 = mg_coarsest(top);
+  if (l == c0) {
+    if (lv.plan.N <= kDenseMax) launch_dense_apply(ctx_.stream, lv.plan.N, m.Ainv.p, b, x, done);
+    else lv.gchol.factor_solve(ctx_.stream, lv.avals.p, b, x, nullptr, false, true);
+    return;
+  }
+  const bool mf = (l == top) && mg_top_matrix_free(top);
+  mg_smooth_pre(lv, mf, b, x, m.r.p, pcg_opt.degree, done);
+  // next level with unknowns below
+  int lc = l - 1;
+  while (lc > c0 && level(lc).plan.N == 0) --lc;
+  Level& lvc = level(lc);
+  // restriction / prolongation compose over skipped (empty) levels never happens for the reference's geometries: adjacent only
+  if (lc != l - 1) throw ArgError("mg: empty intermediate level");
+  launch_spmv(ctx_.stream, lvc.mg->PT.view, m.r.p, nullptr, lvc.mg->b.p);
+  mg_vcycle(top, lc, lvc.mg->b.p, lvc.mg->x.p, done);
+  launch_spmv(ctx_.stream, lvc.mg->P.view, lvc.mg->x.p, x, x);
+  mg_smooth_post(lv, mf, b, x, m.r.p, pcg_opt.degree, done);
+}
+
+// ------------------------------------------------------------------ preconditioned CG on the Newton system of level `top`
+
+bool Amg::pcg_run(Level& lv, int top, const double* g, double* x, SolveStats* st, int* iters, double* relres) {
+  const int N = lv.plan.N;
+  const bool mf = mg_top_matrix_free(top);
+  double* scal = mg_scal_.p;
+  const double* done = scal + SC_DONE;
+  const double t0 = now_s();
+  h_pcg_.p[0] = -1.0;
+  h_pcg_.p[1] = 0.0;
+  launch_pcg_init(ctx_.stream, N, g, x, pcg_r_.p, scal, pcg_opt.rtol, pcg_opt.maxit);
+  mg_vcycle(top, top, pcg_r_.p, pcg_z_.p, done);
+  // completion signals as everywhere else on a single GPU: the dot launch bumps the sequence number the host polls
+  auto sig = [&]() {
+    HostSignal s;
+    s.seq_dev = seq_dev_.p;
+    s.seq_host = h_seq_.p;
+    ++seq_expected_;
+    return s;
+  };
+  launch_pcg_dot(ctx_.stream, N, pcg_r_.p, pcg_z_.p, scal, mg_scratch_.p, h_pcg_.p, sig());
+  launch_pcg_p(ctx_.stream, N, pcg_p_.p, pcg_z_.p, scal);
+  int enq = 0;
+  for (;;) {
+    for (int c = 0; c < std::max(1, pcg_opt.chunk) && enq < pcg_opt.maxit; ++c, ++enq) {
+      MgEpi e;
+      e.mode = MG_PAP;
+      e.n = N;
+      e.v = pcg_p_.p;
+      e.out = pcg_Ap_.p;
+      e.scal = scal;
+      e.scratch = mg_scratch_.p;
+      e.done = done;
+      mg_apply(lv, mf, e);
+      launch_pcg_update(ctx_.stream, N, x, pcg_r_.p, pcg_p_.p, pcg_Ap_.p, scal);
+      mg_vcycle(top, top, pcg_r_.p, pcg_z_.p, done);
+      launch_pcg_dot(ctx_.stream, N, pcg_r_.p, pcg_z_.p, scal, mg_scratch_.p, h_pcg_.p, sig());
+      launch_pcg_p(ctx_.stream, N, pcg_p_.p, pcg_z_.p, scal);
+    }
+    // wait for the batch's last dot (its signal is the newest one expected)
+    {
+      const volatile unsigned long long* q = h_seq_.p;
+      const double tw = now_s();
+      for (unsigned long spins = 0; __atomic_load_n(q, __ATOMIC_ACQUIRE) < seq_expected_; ++spins)
+        if ((spins & 0xfffff) == 0xfffff && now_s() - tw > 10.0) {
+          hip_check(hipStreamSynchronize(ctx_.stream), "sync pcg");
+          if (__atomic_load_n(q, __ATOMIC_ACQUIRE) < seq_expected_) throw InternalError("mgb: completion signal lost in pcg");
+        }
+    }
+    if (h_pcg_.p[1] != 0.0 || enq >= pcg_opt.maxit) break;
+  }
+  const int it = (int)h_pcg_.p[0];
+  const double code = h_pcg_.p[1];
+  if (iters) *iters = it;
+  if (relres) *relres = h_pcg_.p[3] > 0 ? std::sqrt(std::fabs(h_pcg_.p[2]) / h_pcg_.p[3]) : 0.0;
+  if (st) {
+    st->pcg_solves++;
+    st->pcg_iters += std::max(it, 0);
+    st->time_pcg += now_s() - t0;
+  }
+  return code == 1.0;
+}
+
+// ------------------------------------------------------------------ fine-grained entry points (tests, probes)
+
+void Amg::eval_Y_at(Level& lv, const double* s_host) {
+  lv.s_trial.upload(s_host, lv.plan.N);
+  dev_apply(lv, lv.s_trial.p, Dz_.p);
+  launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p);
+}
+
+void Amg::hessian_apply(int l, const double* s_host, const double* v_host, double* out_host, bool matrix_free) {
+  if (ctx_.world > 1) throw ArgError("hessian_apply: single-GPU contexts only");
+  Level& lv = level(l);
+  mg_ensure_vectors(lv);
+  eval_Y_at(lv, s_host);
+  Level::Mg& m = *lv.mg;
+  if (matrix_free && !mg_ensure_elop(lv)) throw ArgError("hessian_apply: the operators of this geometry are not element-local");
+  if (!matrix_free) {
+    mg_ensure_assembled(lv);
+    mg_level_values(lv, false);
+  }
+  m.b.upload(v_host, lv.plan.N);
+  MgEpi e;
+  e.mode = MG_PLAIN;
+  e.n = lv.plan.N;
+  e.v = m.b.p;
+  e.out = m.x.p;
+  mg_apply(lv, matrix_free, e);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync hessian_apply");
+  m.x.download(out_host, lv.plan.N);
+}
+
+double Amg::mg_smooth(int l, const double* s_host, const double* b_host, double* x_host, int degree, int sweeps, double lmax,
+                      bool matrix_free) {
+  if (ctx_.world > 1) throw ArgError("mg_smooth: single-GPU contexts only");
+  if (degree < 1 || degree > kChebMaxDegree) throw ArgError("mg_smooth: degree must be 1..7");
+  Level& lv = level(l);
+  mg_ensure_vectors(lv);
+  eval_Y_at(lv, s_host);
+  Level::Mg& m = *lv.mg;
+  if (matrix_free && !mg_ensure_elop(lv)) throw ArgError("mg_smooth: the operators of this geometry are not element-local");
+  if (!matrix_free) mg_ensure_assembled(lv);
+  mg_level_values(lv, matrix_free);
+  const int keep = pcg_opt.degree;
+  pcg_opt.degree = degree;
+  mg_estimate(lv, matrix_free, lmax);
+  m.b.upload(b_host, lv.plan.N);
+  m.x.upload(x_host, lv.plan.N);
+  for (int sw = 0; sw < sweeps; ++sw) mg_smooth_post(lv, matrix_free, m.b.p, m.x.p, m.r.p, degree, nullptr);
+  pcg_opt.degree = keep;
+  double used = 0;
+  hip_check(hipMemcpyAsync(&used, m.coef.p + kChebStride - 1, sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H lmax");
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync mg_smooth");
+  m.x.download(x_host, lv.plan.N);
+  return used;
+}
+
+void Amg::mg_prolong(int l, const double* xc_host, double* xf_host) {
+  mg_ensure_transfer(l);
+  Level &lc = level(l), &lf = level(l + 1);
+  mg_ensure_vectors(lc);
+  mg_ensure_vectors(lf);
+  lc.mg->x.upload(xc_host, lc.plan.N);
+  launch_spmv(ctx_.stream, lc.mg->P.view, lc.mg->x.p, nullptr, lf.mg->x.p);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync prolong");
+  lf.mg->x.download(xf_host, lf.plan.N);
+}
+
+void Amg::mg_restrict(int l, const double* rf_host, double* rc_host) {
+  mg_ensure_transfer(l);
+  Level &lc = level(l), &lf = level(l + 1);
+  mg_ensure_vectors(lc);
+  mg_ensure_vectors(lf);
+  lf.mg->r.upload(rf_host, lf.plan.N);
+  launch_spmv(ctx_.stream, lc.mg->PT.view, lf.mg->r.p, nullptr, lc.mg->b.p);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync restrict");
+  lc.mg->b.download(rc_host, lc.plan.N);
+}
+
+bool Amg::pcg_solve_linear(int l, const double* s_host, const double* g_host, double* x_host, int* iters, double* relres) {
+  Level& lv = level(l);
+  mg_prepare(l);
+  eval_Y_at(lv, s_host);
+  mg_values(l);
+  lv.g_trial.upload(g_host, lv.plan.N);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync");
+  seq_expected_ = *h_seq_.p;      //  an earlier failed call must not leave the host counter ahead of the device's
+  const bool ok = pcg_run(lv, l, lv.g_trial.p, lv.nstep.p, nullptr, iters, relres);
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync pcg");
+  lv.nstep.download(x_host, lv.plan.N);
+  int fail = 0;
+  hip_check(hipMemcpy(&fail, mg_fail_.p, sizeof(int), hipMemcpyDeviceToHost), "D2H mg flag");
+  if (fail) {
+    hip_check(hipMemset(mg_fail_.p, 0, sizeof(int)), "memset mg flag");
+    throw NumericError("pcg: the coarsest-level matrix is not positive definite");
+  }
+  return ok;
+}
+
+}  // namespace mgb

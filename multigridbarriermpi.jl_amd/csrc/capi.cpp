@@ -33,6 +33,7 @@ struct mgb_amg_s {
   SolveStats stats;
   bool schedule_all = false;
   bool host_solve = false;
+  bool pcg = false;
 };
 struct mgb_plan_s {
   LevelPlan plan;
@@ -839,10 +840,96 @@ int mgb_amg_solve_linear_gpu(mgb_amg a, int level, const double* lower_vals, con
     if (!a->amg->solve_device(level, lower_vals, g, x)) throw NumericError("MfChol: matrix is not positive definite");
   });
 }
-int mgb_amg_set_solver(mgb_amg a, int host) {
+int mgb_amg_set_solver(mgb_amg a, int solver) {
+  return guard([&] {
+    need(a && solver >= 0 && solver <= 2, "set_solver: 0 (device Cholesky), 1 (host Cholesky) or 2 (V-cycle-preconditioned CG)");
+    a->host_solve = solver == 1;
+    a->pcg = solver == 2;
+    a->amg->set_pcg(a->pcg);
+  });
+}
+int mgb_amg_set_pcg(mgb_amg a, double rtol, int maxit, int degree, int power_its, double lo_frac, double hi_frac, int chunk,
+                    int fallback, int assembled_top) {
   return guard([&] {
     need(a, "null amg");
-    a->host_solve = host != 0;
+    PcgOptions& o = a->amg->pcg_opt;
+    if (rtol > 0) o.rtol = rtol;
+    if (maxit > 0) o.maxit = maxit;
+    if (degree > 0) {
+      need(degree <= kChebMaxDegree, "set_pcg: smoothing degree must be 1..7");
+      o.degree = degree;
+    }
+    if (power_its > 0) o.power_its = power_its;
+    if (lo_frac > 0 && hi_frac > lo_frac) {
+      o.lo_frac = lo_frac;
+      o.hi_frac = hi_frac;
+    }
+    if (chunk > 0) o.chunk = chunk;
+    if (fallback >= 0) o.fallback = fallback != 0;
+    if (assembled_top >= 0) o.assembled_top = assembled_top != 0;
+  });
+}
+int mgb_amg_sol_pcg(mgb_amg a, long long* counts3, double* time_s) {
+  return guard([&] {
+    need(a, "null amg");
+    if (counts3) {
+      counts3[0] = a->stats.pcg_solves;
+      counts3[1] = a->stats.pcg_iters;
+      counts3[2] = a->stats.pcg_fallbacks;
+    }
+    if (time_s) *time_s = a->stats.time_pcg;
+  });
+}
+int mgb_hessian_apply(mgb_amg a, int level, const double* s, const double* v, double* Hv, int matrix_free) {
+  return guard([&] {
+    need(a && s && v && Hv && level >= 0 && level < a->amg->L(), "hessian_apply: bad arguments");
+    a->amg->hessian_apply(level, s, v, Hv, matrix_free != 0);
+  });
+}
+int mgb_smooth(mgb_amg a, int level, const double* s, const double* b, double* x, int degree, int sweeps, double lmax,
+               int matrix_free, double* lmax_used) {
+  return guard([&] {
+    need(a && s && b && x && sweeps >= 1 && level >= 0 && level < a->amg->L(), "smooth: bad arguments");
+    const double used = a->amg->mg_smooth(level, s, b, x, degree, sweeps, lmax, matrix_free != 0);
+    if (lmax_used) *lmax_used = used;
+  });
+}
+int mgb_prolong(mgb_amg a, int level, const double* xc, double* xf) {
+  return guard([&] {
+    need(a && xc && xf && level >= 0 && level + 1 < a->amg->L(), "prolong: bad arguments");
+    a->amg->mg_prolong(level, xc, xf);
+  });
+}
+int mgb_restrict(mgb_amg a, int level, const double* rf, double* rc) {
+  return guard([&] {
+    need(a && rf && rc && level >= 0 && level + 1 < a->amg->L(), "restrict: bad arguments");
+    a->amg->mg_restrict(level, rf, rc);
+  });
+}
+int mgb_amg_prolongation(mgb_amg a, int level, int* rows, int* cols, int* nnz, int32_t* rowptr, int32_t* colidx, double* vals) {
+  return guard([&] {
+    need(a && level >= 0 && level + 1 < a->amg->L(), "prolongation: bad arguments");
+    const Csr& P = a->amg->prolongation_host(level);
+    if (rows) *rows = P.rows;
+    if (cols) *cols = P.cols;
+    if (nnz) *nnz = P.nnz();
+    if (rowptr) std::copy(P.rowptr.begin(), P.rowptr.end(), rowptr);
+    if (colidx) std::copy(P.colidx.begin(), P.colidx.end(), colidx);
+    if (vals) std::copy(P.vals.begin(), P.vals.end(), vals);
+  });
+}
+int mgb_amg_pcg_solve_linear(mgb_amg a, int level, const double* s, const double* g, double* x, int* iters, double* relres,
+                             int* converged) {
+  return guard([&] {
+    need(a && s && g && x && level >= 0 && level < a->amg->L(), "pcg_solve_linear: bad arguments");
+    const bool ok = a->amg->pcg_solve_linear(level, s, g, x, iters, relres);
+    if (converged) *converged = ok ? 1 : 0;
+  });
+}
+int mgb_amg_mg_info(mgb_amg a, int top, int* coarsest) {
+  return guard([&] {
+    need(a && top >= 0 && top < a->amg->L(), "mg_info: bad arguments");
+    if (coarsest) *coarsest = a->amg->mg_coarsest(top);
   });
 }
 int mgb_amg_set_schedule(mgb_amg a, int all_levels) {
@@ -857,6 +944,7 @@ int mgb_amg_solve(mgb_amg a, double tol, double t0, double kappa, int maxit, int
     SolveOptions o;
     o.schedule_all = a->schedule_all;
     o.host_solve = a->host_solve;
+    o.pcg = a->pcg;
     if (tol > 0) o.tol = tol;
     if (t0 > 0) o.t0 = t0;
     if (kappa > 1) o.kappa = kappa;
@@ -913,6 +1001,19 @@ int mgb_amg_time_kernels(mgb_amg a, int level, int reps, int nrot, double* ms8, 
 }
 
 // ---- host-only helpers
+int mgb_plan_prolongation(mgb_plan fine, mgb_plan coarse, int* rows, int* cols, int* nnz, int32_t* rowptr, int32_t* colidx,
+                          double* vals) {
+  return guard([&] {
+    need(fine && coarse, "null plan");
+    Csr P = build_prolongation(fine->plan.R, coarse->plan.R);
+    if (rows) *rows = P.rows;
+    if (cols) *cols = P.cols;
+    if (nnz) *nnz = P.nnz();
+    if (rowptr) std::copy(P.rowptr.begin(), P.rowptr.end(), rowptr);
+    if (colidx) std::copy(P.colidx.begin(), P.colidx.end(), colidx);
+    if (vals) std::copy(P.vals.begin(), P.vals.end(), vals);
+  });
+}
 int mgb_plan_create(mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D, int nq,
                     const int* idx_q, int idx_s, int level, mgb_plan* out) {
   return guard([&] {

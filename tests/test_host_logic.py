@@ -337,3 +337,49 @@ def test_julia_shim_binds_only_declared_entry_points(lib):
                  "_raw_array", "_to_cpu_array", "_rows_to_svectors", "MultiGridBarrier.solve", "native_to_hip", "hip_to_native"):
         assert re.search(r"^\s*(function\s+)?%s\(" % re.escape(hook), src, re.M), hook
     assert len(src.splitlines()) <= 320
+
+
+@pytest.mark.parametrize("kind,L", [("fem1d", 5), ("fem2d", 4), ("fem3d", 2)])
+def test_prolongation_between_level_plans(kind, L):
+    """SURVEY.md section 8 a11, host part: the AMG levels are nested, R_l = R_{l+1} P_l, and the library reads P_l off the
+    nodes that carry a level-(l+1) unknown alone.  Checked through apply_D's matrix B = D R (host products of the plans):
+    B_{l+1} (P s) = B_l s for random s, at every level."""
+    from mgb_amd import _lib
+    call, dptr, iptr = _lib.call, _lib.dptr, _lib.iptr
+    g = C.c_void_p()
+    if kind == "fem1d":
+        call("mgb_fem1d_native", L, C.byref(g))
+        state, D, idx = (("u", "dirichlet"), ("s", "full")), (("u", "id"), ("u", "dx"), ("s", "id")), [1, 2]
+    elif kind == "fem2d":
+        call("mgb_fem2d_native", L, None, 0, C.byref(g))
+        state, D, idx = (("u", "dirichlet"), ("s", "full")), (("u", "id"), ("u", "dx"), ("u", "dy"), ("s", "id")), [1, 2, 3]
+    else:
+        call("mgb_fem3d_native", L, 2, C.byref(g))
+        state = (("u", "dirichlet"), ("s", "full"))
+        D, idx = (("u", "id"), ("u", "dx"), ("u", "dy"), ("u", "dz"), ("s", "id")), [1, 2, 3, 4]
+    n = C.c_int()
+    call("mgb_geo_dims", g, C.byref(n), None, None, None)
+    plans = []
+    for l in range(L):
+        p = C.c_void_p()
+        iq = (C.c_int * (len(idx) - 1))(*idx[:-1])
+        call("mgb_plan_create", g, len(state), _lib.str_array(state), len(D), _lib.str_array(D), len(idx) - 1, iq, idx[-1], l,
+             C.byref(p))
+        plans.append(p)
+    rng = np.random.default_rng(0)
+    K = len(D)
+    for l in range(L - 1):
+        r, c, nz = C.c_int(), C.c_int(), C.c_int()
+        call("mgb_plan_prolongation", plans[l + 1], plans[l], C.byref(r), C.byref(c), C.byref(nz), None, None, None)
+        rp, ci, va = np.empty(r.value + 1, dtype=np.int32), np.empty(nz.value, dtype=np.int32), np.empty(nz.value)
+        call("mgb_plan_prolongation", plans[l + 1], plans[l], None, None, None, iptr(rp), iptr(ci), dptr(va))
+        P = sp.csr_matrix((va, ci, rp), shape=(r.value, c.value))
+        s = rng.standard_normal(c.value)
+        Bc, Bf = np.empty(n.value * K), np.empty(n.value * K)
+        call("mgb_plan_apply_B_host", plans[l], dptr(s), dptr(Bc))
+        call("mgb_plan_apply_B_host", plans[l + 1], dptr(np.ascontiguousarray(P @ s)), dptr(Bf))
+        assert np.abs(Bf - Bc).max() <= 1e-12 * np.abs(Bc).max()
+        assert P.nnz < 12 * r.value        # local interpolation, not a dense map
+    for p in plans:
+        call("mgb_plan_destroy", p)
+    call("mgb_geo_destroy", g)
