@@ -54,6 +54,14 @@ int mgb_ctx_synchronize(mgb_ctx ctx);
  * (default) never calls it. */
 typedef int (*mgb_allreduce_fn)(void* user, double* dev_ptr, long long count);
 int mgb_ctx_set_comm(mgb_ctx ctx, int rank, int world, mgb_allreduce_fn fn, void* user);
+/* The same sharding with a communicator the LIBRARY owns (RCCL over xGMI; the reference's collectives are in-library too,
+ * src:125,132): rank 0 calls mgb_rccl_unique_id (128 bytes) and hands the id to the other ranks by whatever channel the host
+ * has (MPI_Bcast, torch.distributed broadcast, a file); every rank then calls mgb_ctx_set_comm_rccl -> ncclCommInitRank.  All
+ * collectives of the Newton path become ncclAllReduce calls enqueued on the context stream: no host synchronisation around
+ * them and no callback into the host language.  librccl is opened at run time (MGB_RCCL_LIB overrides the name); MGB_E_HIP if
+ * it cannot be opened.  world == 1 is allowed (one-rank communicator; mgb_vec_allreduce_sum then runs through RCCL). */
+int mgb_rccl_unique_id(char* out128);
+int mgb_ctx_set_comm_rccl(mgb_ctx ctx, const char* unique_id128, int rank, int world);
 int mgb_ctx_comm_stats(mgb_ctx ctx, long long* calls, double* bytes);
 int mgb_shard_rows(int rank, int world, int n, int block, int* r0, int* r1);
 
@@ -191,6 +199,12 @@ int mgb_amg_set_solver(mgb_amg a, int solver);
 /* amgb_step level schedule: 0 (default) = Newton on the finest subspace only, 1 = literal coarse -> fine
  * level loop (R_1 ... R_L).  Both end at the same z; see DESIGN.md section 2. */
 int mgb_amg_set_schedule(mgb_amg a, int all_levels);
+/* end of the t-continuation: 0 (default) = at the fixed t_stop = the first value of t0 kappa^k beyond 1/tol, the last step
+ * clipped to land on it (the end point, and z to ~1e-6 at p = 1, then no longer hangs on the history of kappa reductions);
+ * 1 = the literal loop of SURVEY.md Appendix A, `while t <= 1/tol: t <- kappa t`.  Neither is confirmed by anything in the
+ * reference ([UPSTREAM-UNVERIFIED]; SOL_main.ts is an observable, docs/src/api.md:97-101); both visit the same ts when kappa is
+ * never reduced. */
+int mgb_amg_set_stop_rule(mgb_amg a, int upstream);
 /* amgb main phase: t-continuation x level loop x Newton; z updated in place */
 int mgb_amg_solve(mgb_amg a, double tol, double t0, double kappa, int maxit, int max_newton, int verbose);
 /* feasibility phases (SOL_feasibility, src:428-455): make mgb_amg_solve return after the first centering at which row `col`
@@ -240,11 +254,18 @@ int mgb_amg_pcg_solve_linear(mgb_amg a, int level, const double* s, const double
 /* CG / V-cycle parameters (a value <= 0, or < 0 for the two flags, keeps the current one): relative tolerance on
  * sqrt(<r, M r>), iteration cap, applications of H per Chebyshev pre-/post-smoothing, power steps per level and Newton matrix,
  * Chebyshev interval fractions, CG iterations enqueued between two looks at the convergence flag, direct solve of a step whose
- * CG did not converge, top level through its assembled matrix instead of the matrix-free product */
+ * CG did not converge, top level through its assembled matrix instead of the matrix-free product, consecutive non-converged
+ * systems after which the rest of the solve goes to the direct solver (0 = keep trying) */
 int mgb_amg_set_pcg(mgb_amg a, double rtol, int maxit, int degree, int power_its, double lo_frac, double hi_frac, int chunk,
-                    int fallback, int assembled_top);
-/* of the last mgb_amg_solve with solver 2: counts3 = {Newton systems, CG iterations, direct fallbacks}, seconds inside CG */
-int mgb_amg_sol_pcg(mgb_amg a, long long* counts3, double* time_s);
+                    int fallback, int assembled_top, int giveup);
+/* of the last mgb_amg_solve with solver 2: counts4 = {Newton systems CG was tried on, CG iterations, direct fallbacks, the
+ * Newton system after which the solve went to the direct solver for good (-1: never)}, seconds inside CG */
+int mgb_amg_sol_pcg(mgb_amg a, long long* counts4, double* time_s);
+/* HIP-event timing of the multigrid kernels at `level` (the Hessian of the current z), `reps` back-to-back launches rotating
+ * over `nrot` distinct copies of the operands (as mgb_amg_time_kernels), ms / bytes moved by construction / algorithmic bytes
+ * (the CSR-based figure of SURVEY.md section 8d) per call: [0] H v matrix-free, [1] one Chebyshev step on it, [2] H v through the
+ * assembled CSR, [3] prolongation from level - 1, [4] restriction to level - 1, [5] bytes of the unfused CSR sequence for H v */
+int mgb_amg_time_mg_kernels(mgb_amg a, int level, int reps, int nrot, double* ms6, double* bytes6, double* alg6);
 /* coarsest level of the V-cycle whose top is level `top` (the largest level with at most 128 unknowns; dense inverse there) */
 int mgb_amg_mg_info(mgb_amg a, int top, int* coarsest);
 

@@ -80,6 +80,17 @@ class HPCBackend:
         call("mgb_ctx_set_comm", self.handle, int(rank), int(world), self._allreduce_cb, None)
         self.rank, self.world = int(rank), int(world)
 
+    def set_comm_rccl(self, rank: int, world: int, unique_id: bytes):
+        """The same sharding with a communicator the library owns (mgb_ctx_set_comm_rccl -> ncclCommInitRank): every
+        collective of the Newton path is an ncclAllReduce on the context stream, no host synchronisation and no Python in the
+        loop.  `unique_id` = the 128 bytes rank 0 got from `rccl_unique_id()`, handed to all ranks by the host's own channel
+        (see `rccl_comm_from_torch`)."""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of rccl_unique_id()")
+        call("mgb_ctx_set_comm_rccl", self.handle, bytes(unique_id), int(rank), int(world))
+        self._allreduce_cb = None
+        self.rank, self.world = int(rank), int(world)
+
     def comm_stats(self):
         n, b = C.c_longlong(), C.c_double()
         call("mgb_ctx_comm_stats", self.handle, C.byref(n), C.byref(b))
@@ -122,6 +133,26 @@ def torch_allreduce(dist, device: int, group=None):
         torch.cuda.synchronize(device)
 
     return allreduce
+
+
+def rccl_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (call on rank 0, broadcast the 128 bytes)."""
+    buf = C.create_string_buffer(128)
+    call("mgb_rccl_unique_id", buf)
+    return buf.raw
+
+
+def rccl_comm_from_torch(backend: "HPCBackend", dist, group=None):
+    """Give `backend` a library-owned RCCL communicator over the ranks of a torch.distributed job: rank 0 draws the unique id,
+    torch.distributed only broadcasts its 128 bytes (setup-time plumbing; nothing of torch stays in the Newton loop)."""
+    import torch
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = torch.device("cuda", backend.device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        t = torch.tensor(list(rccl_unique_id()), dtype=torch.uint8, device=dev)
+    dist.broadcast(t, src=0, group=group)
+    backend.set_comm_rccl(rank, world, bytes(t.cpu().tolist()))
 
 
 _BACKENDS: Dict[int, HPCBackend] = {}
@@ -949,11 +980,11 @@ class AMG:
         call("mgb_amg_set_solver", self.handle, self.SOLVERS[solver])
 
     def set_pcg(self, rtol=0.0, maxit=0, degree=0, power_its=0, lo_frac=0.0, hi_frac=0.0, chunk=0, fallback=None,
-                assembled_top=None):
+                assembled_top=None, giveup=-1):
         """Parameters of solver="pcg" (unset ones keep their value): see mgb_amg_set_pcg."""
         flag = lambda v: -1 if v is None else int(bool(v))
         call("mgb_amg_set_pcg", self.handle, float(rtol), int(maxit), int(degree), int(power_its), float(lo_frac),
-             float(hi_frac), int(chunk), flag(fallback), flag(assembled_top))
+             float(hi_frac), int(chunk), flag(fallback), flag(assembled_top), int(giveup))
 
     # ---- multigrid pieces (SURVEY.md section 8 a11): mgb_hessian_apply / mgb_smooth / mgb_prolong / mgb_restrict
     def hessian_apply(self, l, s, v, matrix_free=True):
@@ -1000,15 +1031,26 @@ class AMG:
         call("mgb_amg_pcg_solve_linear", self.handle, l, dptr(s), dptr(g), dptr(x), C.byref(it), C.byref(rr), C.byref(ok))
         return x, it.value, rr.value, bool(ok.value)
 
+    MG_KERNEL_NAMES = ("hessian_apply", "chebyshev_step", "hessian_apply_csr", "prolong", "restrict", "hessian_apply_unfused_csr")
+
+    def time_mg_kernels(self, l, reps=50, nrot=1):
+        """HIP-event timing of the multigrid kernels at level l (rotating operand copies as time_kernels)."""
+        ms, by, alg = np.empty(6), np.empty(6), np.empty(6)
+        call("mgb_amg_time_mg_kernels", self.handle, int(l), int(reps), int(nrot), dptr(ms), dptr(by), dptr(alg))
+        return {k: dict(ms=float(a), bytes=float(b), algorithmic_bytes=float(c)) for k, a, b, c in zip(self.MG_KERNEL_NAMES, ms, by, alg)}
+
     def mg_coarsest(self, top=None):
         c0 = C.c_int()
         call("mgb_amg_mg_info", self.handle, self.L - 1 if top is None else int(top), C.byref(c0))
         return c0.value
 
     def solve(self, tol=None, t=0.1, kappa=10.0, maxit=10000, max_newton=0, verbose=0, schedule="fine",
-              solver="gpu"):
+              solver="gpu", stop_rule="fixed"):
         if schedule not in ("fine", "all"):
             raise ValueError("schedule must be 'fine' or 'all'")
+        if stop_rule not in ("fixed", "upstream"):
+            raise ValueError("stop_rule must be 'fixed' or 'upstream'")
+        call("mgb_amg_set_stop_rule", self.handle, 1 if stop_rule == "upstream" else 0)
         call("mgb_amg_set_schedule", self.handle, 1 if schedule == "all" else 0)
         self.set_solver(solver)
         call("mgb_amg_solve", self.handle, float(tol or 0.0), float(t), float(kappa), int(maxit), int(max_newton),
@@ -1026,12 +1068,12 @@ class AMG:
         call("mgb_amg_sol_kernels", self.handle, dptr(kms), dptr(kby), kl.ctypes.data_as(_lib.c_ll_p))
         kernels = {k: dict(ms=float(m), bytes=float(b), launches=int(c))
                    for k, m, b, c in zip(self.KERNEL_NAMES, kms, kby, kl)}
-        pc = (C.c_longlong * 3)()
+        pc = (C.c_longlong * 4)()
         tp = C.c_double()
         call("mgb_amg_sol_pcg", self.handle, pc, C.byref(tp))
         return dict(t_elapsed=te.value, ts=ts, its=its.reshape(nt.value, self.L).T.copy(), c_dot_Dz=cd,
                     time_factor=tf.value, n_f0=counts[0], n_f1=counts[1], n_f2=counts[2], n_factor=counts[3],
-                    kernels=kernels, pcg=dict(solves=pc[0], iterations=pc[1], fallbacks=pc[2], seconds=tp.value))
+                    kernels=kernels, pcg=dict(solves=pc[0], iterations=pc[1], fallbacks=pc[2], gave_up_at=pc[3], seconds=tp.value))
 
     KERNEL_NAMES = ("apply_D", "barrier_f2", "hessian_assemble", "barrier_f1", "restrict", "barrier_f0",
                     "chol_front_start", "chol_front_step", "chol_backward_rect", "chol_backward", "chol_front_single")
@@ -1111,7 +1153,8 @@ def _phase1_slack(geometry, M: "AMG", p, z0, c, tol, schedule, solver):
 
 
 def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=None, g=None, tol=None, t=0.1,
-         maxit=10000, kappa=10.0, verbose=False, logfile=None, schedule="fine", solver="gpu", cones=None, **rest) -> AMGBSOL:
+         maxit=10000, kappa=10.0, verbose=False, logfile=None, schedule="fine", solver="gpu", cones=None, stop_rule="fixed",
+         **rest) -> AMGBSOL:
     """MultiGridBarrier.amgb on an MPI geometry (called at src:599,666).  kwargs as documented in
     docs/src/guide.md:148-152; unknown kwargs (e.g. `L`, forwarded by fem*d_mpi_solve, src:663-666)
     are ignored like Julia's `kwargs...` fan-out.  `cones` (upstream kwarg `Q`: the convex set) selects the barrier terms,
@@ -1162,7 +1205,7 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
         M.set_pcg(**rest["pcg"])      # parameters of solver="pcg", see AMG.set_pcg
     M.prepare()       # factorisation structures are setup, not solve time (SOL_main.t_elapsed mirrors the reference's)
     SOL = M.solve(tol=tol, t=t, kappa=kappa, maxit=maxit, verbose=2 if verbose and verbose > 1 else int(bool(verbose)),
-                  schedule=schedule, solver=solver)
+                  schedule=schedule, solver=solver, stop_rule=stop_rule)
     z = M.get_z().reshape(z0.shape, order="F")
     return AMGBSOL(HPCMatrix(z, geometry.x.backend), SOL_feasibility, SOL, [], geometry)
 

@@ -32,6 +32,8 @@ PROTOTYPES = {
     "mgb_ctx_destroy": [H],
     "mgb_ctx_synchronize": [H],
     "mgb_ctx_set_comm": [H, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p],
+    "mgb_rccl_unique_id": [C.c_char_p],
+    "mgb_ctx_set_comm_rccl": [H, C.c_char_p, C.c_int, C.c_int],
     "mgb_ctx_comm_stats": [H, c_ll_p, c_dbl_p],
     "mgb_shard_rows": [C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p],
     "mgb_fem1d_native": [C.c_int, C.POINTER(H)],
@@ -103,7 +105,8 @@ PROTOTYPES = {
     "mgb_amg_solve_linear_gpu": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],
     "mgb_amg_set_solver": [H, C.c_int],
     "mgb_amg_set_schedule": [H, C.c_int],
-    "mgb_amg_set_pcg": [H, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int],
+    "mgb_amg_set_stop_rule": [H, C.c_int],
+    "mgb_amg_set_pcg": [H, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int],
     "mgb_amg_sol_pcg": [H, c_ll_p, c_dbl_p],
     "mgb_hessian_apply": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, C.c_int],
     "mgb_smooth": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, C.c_int, C.c_int, C.c_double, C.c_int, c_dbl_p],
@@ -112,6 +115,7 @@ PROTOTYPES = {
     "mgb_amg_prolongation": [H, C.c_int, c_int_p, c_int_p, c_int_p, c_i32_p, c_i32_p, c_dbl_p],
     "mgb_amg_pcg_solve_linear": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_int_p, c_dbl_p, c_int_p],
     "mgb_amg_mg_info": [H, C.c_int, c_int_p],
+    "mgb_amg_time_mg_kernels": [H, C.c_int, C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p],
     "mgb_plan_prolongation": [H, H, c_int_p, c_int_p, c_int_p, c_i32_p, c_i32_p, c_dbl_p],
     "mgb_amg_solve": [H, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int],
     "mgb_amg_sol_info": [H, c_int_p, c_dbl_p, c_dbl_p, c_ll_p],

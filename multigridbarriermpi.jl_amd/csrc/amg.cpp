@@ -28,15 +28,20 @@ Ctx::Ctx(int dev) : device(dev) {
 }
 
 Ctx::~Ctx() {
+  drop_comm();
   if (stream) (void)hipStreamDestroy(stream);
 }
 
-void Ctx::allreduce_sum(double* dev_ptr, long long count) {
-  if (world <= 1 || count <= 0) return;
-  if (!allreduce) throw ArgError("mgb: sharded context without an allreduce callback");
-  hip_check(hipStreamSynchronize(stream), "sync before allreduce");
-  const int rc = allreduce(allreduce_user, dev_ptr, count);
-  if (rc != 0) throw InternalError("mgb: allreduce callback failed with code " + std::to_string(rc));
+void Ctx::allreduce_sum(double* dev_ptr, long long count, bool even_single) {
+  if ((world <= 1 && !(even_single && rccl_comm)) || count <= 0) return;
+  if (rccl_comm) {
+    rccl_allreduce(dev_ptr, count);      // stream ordered: the launches around it need no host synchronisation
+  } else {
+    if (!allreduce) throw ArgError("mgb: sharded context without a communicator (mgb_ctx_set_comm_rccl / mgb_ctx_set_comm)");
+    hip_check(hipStreamSynchronize(stream), "sync before allreduce");
+    const int rc = allreduce(allreduce_user, dev_ptr, count);
+    if (rc != 0) throw InternalError("mgb: allreduce callback failed with code " + std::to_string(rc));
+  }
   n_allreduce++;
   allreduce_bytes += 8.0 * count;
 }
@@ -863,10 +868,23 @@ bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, do
     // exactly as behind the direct solver.  A CG that stops without converging hands the step to the device Cholesky.
     const int top = level_index(lv);
     bool ok = pcg_run(lv, top, lv.g.p, lv.nstep.p, &st, nullptr, nullptr);
+    if (!ok && pcg_last_code_ == 2.0) {
+      // breakdown: an eigenvalue estimate that fell short makes the smoother amplify the top modes and the V-cycle
+      // indefinite.  Estimate again from the fixed start vector with the full number of power steps, once.
+      for (int l = mg_coarsest(top); l <= top; ++l)
+        if (level(l).mg) level(l).mg->ev_warm = false;
+      mg_values(top);
+      ok = pcg_run(lv, top, lv.g.p, lv.nstep.p, &st, nullptr, nullptr);
+    }
     h_flag_.p[0] = 0;
+    if (ok) pcg_bad_streak_ = 0;
     if (!ok) {
       if (!pcg_opt.fallback) return false;
       st.pcg_fallbacks++;
+      if (pcg_opt.giveup > 0 && ++pcg_bad_streak_ >= pcg_opt.giveup) {
+        pcg_ = false;      // from the gradient of this step on, everything (assembly, speculation, graphs) is the direct path
+        st.pcg_gaveup_at = st.n_factor;
+      }
       ensure_chol(lv);
       launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
       lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g.p, lv.nstep.p, nullptr, false);
@@ -1193,6 +1211,7 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   schedule_all_ = opt.schedule_all;
   host_solve_ = opt.host_solve;
   pcg_ = opt.pcg && !opt.host_solve;
+  pcg_bad_streak_ = 0;
   if (pcg_ && ctx_.world > 1) throw ArgError("amgb: solver pcg runs on single-GPU contexts (sharded contexts use the direct solver)");
   if (pcg_)
     for (int J = (schedule_all_ ? 0 : L - 1); J < L; ++J)
@@ -1219,11 +1238,13 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   while (t_stop <= 1 / opt.tol) t_stop *= kappa0;
   if (early_stop_col_ >= P_.K) throw ArgError("amgb: early-stop column out of range");
   bool stopped = early_stop_col_ >= 0 && slack_negative();
-  while (t < t_stop && kappa > 1 && k < opt.maxit && !stopped) {
+  const bool fixed = !opt.upstream_stop;
+  auto going = [&](double tt) { return fixed ? tt < t_stop : tt <= 1 / opt.tol; };
+  while (going(t) && kappa > 1 && k < opt.maxit && !stopped) {
     k++;
     std::fill(its.begin(), its.end(), 0);
     while (kappa > 1) {
-      const double t1 = std::min(kappa * t, t_stop);
+      const double t1 = fixed ? std::min(kappa * t, t_stop) : kappa * t;
       hip_check(hipMemcpyAsync(z_save_.p, z_.p, zbytes, hipMemcpyDeviceToDevice, ctx_.stream), "save z");
       hip_check(hipMemcpyAsync(Dz0_save_.p, Dz0_.p, dzbytes, hipMemcpyDeviceToDevice, ctx_.stream), "save Dz0");
       std::vector<long long> it1(L, 0);
@@ -1254,7 +1275,7 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   }
   hip_check(hipStreamSynchronize(ctx_.stream), "sync");
   st.t_elapsed = now_s() - t_begin;
-  if (t < t_stop && !stopped) throw NumericError("amgb: convergence failure (kappa collapsed)");
+  if (going(t) && !stopped) throw NumericError("amgb: convergence failure (kappa collapsed)");
 }
 
 // ------------------------------------------------------------------ fine-grained entry points

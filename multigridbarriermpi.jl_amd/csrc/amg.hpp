@@ -42,10 +42,18 @@ struct Ctx {
   void* allreduce_user = nullptr;
   long long n_allreduce = 0;
   double allreduce_bytes = 0;
+  // library-owned RCCL communicator (comm.cpp): when set, the collectives are ncclAllReduce on `stream` -- no host sync, no callback
+  void* rccl_comm = nullptr;
   explicit Ctx(int dev);
   ~Ctx();
-  void allreduce_sum(double* dev_ptr, long long count);
+  // even_single: run the collective although world == 1 (a one-rank communicator under test)
+  void allreduce_sum(double* dev_ptr, long long count, bool even_single = false);
+  void set_comm_rccl(const char* id128, int rank, int world);
+  void drop_comm();
+ private:
+  void rccl_allreduce(double* dev_ptr, long long count);
 };
+void rccl_unique_id(char* out128);
 
 template <class T>
 struct DevBuf {
@@ -134,10 +142,17 @@ struct PcgOptions {
   double rtol = 1e-9;      // on sqrt(<r, M r> / <r0, M r0>)
   int maxit = 200;
   int degree = 2;          // operator applications per Chebyshev pre- / post-smoothing
-  int power_its = 6;       // power steps per level and Newton matrix for lambda_max(Dinv A) (warm-started)
-  double lo_frac = 0.1, hi_frac = 1.1;      // Chebyshev interval as fractions of the estimate
+  int power_its = 6;       // power steps per level and Newton matrix for lambda_max(Dinv A), warm-started from the last matrix's vector
+  int power_its_cold = 24; // ... and from the fixed start vector (first matrix of a level, or after a breakdown)
+  // Chebyshev interval as fractions of the estimate.  The power steps approach lambda_max from below (measured: 0.82-0.95 of it
+  // after 6 cold steps, 0.98 after 24, profiles/r3_mg_eig_probe.txt); an interval that ends below lambda_max makes the smoother
+  // amplify the top modes and the V-cycle indefinite, hence the margin.
+  double lo_frac = 0.12, hi_frac = 1.2;
   int chunk = 4;           // CG iterations enqueued between two looks at the convergence flag
   bool fallback = true;    // direct solve of the step when CG stops without converging
+  // after this many consecutive Newton systems on which CG did not converge, the rest of the solve goes to the direct solver
+  // without trying (the barrier Hessians only get harder as t grows); 0 = never give up
+  int giveup = 3;
   bool assembled_top = false;      // finest level through its assembled matrix instead of the matrix-free product (A/B runs)
 };
 
@@ -192,6 +207,10 @@ struct SolveOptions {
   bool pcg = false;                     // true: V-cycle-preconditioned CG on the GPU (PcgOptions of the Amg)
   bool schedule_all = false;            // false: finest level only; true: coarse -> fine level loop
   bool time_kernels = true;             // bracket kernels with HIP events (a few us of host time per step)
+  // end of the t-continuation (both [UPSTREAM-UNVERIFIED], oracle STOP_RULE): false = at the fixed t_stop, the first value of
+  // t0 kappa^k beyond 1 / tol, last step clipped (end point independent of the history of kappa reductions); true = the literal
+  // loop `while t <= 1 / tol: t <- kappa t`.  Same ts whenever kappa is never reduced.
+  bool upstream_stop = false;
   double tol = 1.4901161193847656e-08;  // sqrt(eps)
   double t0 = 0.1;
   double kappa = 10.0;
@@ -208,6 +227,7 @@ struct SolveStats {
   double time_factor = 0, time_device = 0;
   long long n_factor = 0, n_f0 = 0, n_f1 = 0, n_f2 = 0;
   long long pcg_solves = 0, pcg_iters = 0, pcg_fallbacks = 0;      // solver = pcg: Newton systems, CG iterations, direct fallbacks
+  long long pcg_gaveup_at = -1;      // Newton system (1-based count) after which the solve went to the direct solver for good
   double time_pcg = 0;
   // live HIP-event timing of the six kernel classes over the solve (KernelClass order)
   double kern_ms[KC_COUNT] = {};
@@ -328,7 +348,7 @@ class Amg {
       DevBuf<int> amap, diagpos, lo_rowptr, lo_colidx;
       DevCsrOwned P, PT;              // prolongation to level l + 1 (N_{l+1} x N_l) and its transpose
       DevBuf<double> dinv, x, b, r, d0, d1, ev0, ev1, coef, Ainv;
-      double lmax_host = 0;
+      bool ev_warm = false;           // ev0 holds the dominant vector of an earlier matrix of this level
     };
     std::unique_ptr<Mg> mg;
   };
@@ -402,6 +422,16 @@ class Amg {
   // x = H(s)^{-1} g by V-cycle-preconditioned CG at level l; returns false if it stopped without converging
   bool pcg_solve_linear(int l, const double* s_host, const double* g_host, double* x_host, int* iters, double* relres);
   const Csr& prolongation_host(int l);      // P_l as built on the host (tests)
+  // HIP-event timing of the multigrid kernels at level l (Y of the current z), `reps` back-to-back launches rotating over `nrot`
+  // distinct copies of the operands (as time_kernels): ms and bytes per call of
+  //   [0] H v matrix-free (element pass + dof gather), [1] one Chebyshev step on it (the same two launches with the fused update),
+  //   [2] H v through the assembled CSR, [3] prolongation from level l - 1, [4] restriction to level l - 1,
+  //   [5] H v as the unfused sequence apply_D-class SpMV on B, block multiply, SpMV on B' would cost it (bytes only; ms = 0)
+  // bytes[0..1]: what the kernels move by construction; alg[0..1]: the CSR-based figure of SURVEY.md section 8(d)
+  struct MgKernelTimes {
+    double ms[6], bytes[6], alg[6];
+  };
+  MgKernelTimes time_mg_kernels(int l, int reps, int nrot);
 
  private:
   Level::Mg& mg_of(Level& lv);
@@ -426,6 +456,8 @@ class Amg {
   DevBuf<int> mg_fail_;
   bool mg_inited_ = false;
   bool pcg_ = false;
+  double pcg_last_code_ = 0;      // stop code of the last CG: 1 converged, 2 breakdown, 3 iteration cap
+  int pcg_bad_streak_ = 0;
 
   Ctx& ctx_;
   int n_ = 0, S_ = 0;

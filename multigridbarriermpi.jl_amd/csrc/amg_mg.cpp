@@ -358,7 +358,9 @@ void Amg::mg_estimate(Level& lv, bool mf, double lmax_given) {
     return;
   }
   launch_power_start(ctx_.stream, N, m.ev0.p, m.dinv.p, mg_scal_.p, mg_scratch_.p);
-  for (int it = 0; it < pcg_opt.power_its; ++it) {
+  const int nsteps = m.ev_warm ? pcg_opt.power_its : std::max(pcg_opt.power_its, pcg_opt.power_its_cold);
+  m.ev_warm = true;
+  for (int it = 0; it < nsteps; ++it) {
     MgEpi e;
     e.mode = MG_POWER;
     e.n = N;
@@ -512,6 +514,11 @@ bool Amg::pcg_run(Level& lv, int top, const double* g, double* x, SolveStats* st
   }
   const int it = (int)h_pcg_.p[0];
   const double code = h_pcg_.p[1];
+  static const bool dbg = std::getenv("MGB_PCG_DEBUG") != nullptr;
+  if (dbg)
+    std::fprintf(stderr, "[mgb pcg] level %d N=%d: %d iterations, stop code %g (1 converged, 2 breakdown, 3 maxit), <r,Mr> %.3e of %.3e\n",
+                 top, N, it, code, h_pcg_.p[2], h_pcg_.p[3]);
+  pcg_last_code_ = code;
   if (iters) *iters = it;
   if (relres) *relres = h_pcg_.p[3] > 0 ? std::sqrt(std::fabs(h_pcg_.p[2]) / h_pcg_.p[3]) : 0.0;
   if (st) {
@@ -597,6 +604,155 @@ void Amg::mg_restrict(int l, const double* rf_host, double* rc_host) {
   launch_spmv(ctx_.stream, lc.mg->PT.view, lf.mg->r.p, nullptr, lc.mg->b.p);
   hip_check(hipStreamSynchronize(ctx_.stream), "sync restrict");
   lc.mg->b.download(rc_host, lc.plan.N);
+}
+
+Amg::MgKernelTimes Amg::time_mg_kernels(int l, int reps, int nrot) {
+  if (ctx_.world > 1) throw ArgError("time_mg_kernels: single-GPU contexts only");
+  Level& lv = level(l);
+  mg_ensure_vectors(lv);
+  if (!mg_ensure_elop(lv)) throw ArgError("time_mg_kernels: the operators of this geometry are not element-local");
+  mg_ensure_assembled(lv);
+  const bool has_coarse = l > 0 && level(l - 1).plan.N > 0;
+  if (has_coarse) {
+    mg_ensure_transfer(l - 1);
+    mg_ensure_vectors(level(l - 1));
+  }
+  if (nrot < 1) nrot = 1;
+  Level::Mg& m = *lv.mg;
+  const int N = lv.plan.N, nY = P_.nY();
+  const DevElOp& E0 = m.elop.view;
+  // the point: s = 0 of the current z
+  hip_check(hipMemsetAsync(lv.s_trial.p, 0, (size_t)N * sizeof(double), ctx_.stream), "memset");
+  dev_apply(lv, lv.s_trial.p, Dz_.p);
+  launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p);
+  mg_level_values(lv, true);       // dinv
+  mg_level_values(lv, false);      // assembled values
+  mg_estimate(lv, true, 0.0);      // Chebyshev coefficients
+  struct Set {
+    DevBuf<double> Bvals, Y, v, out, elbuf, x, r, d, Avals;
+    DevCsrOwned P, PT;
+    DevBuf<double> xc, bc;
+  };
+  std::vector<std::unique_ptr<Set>> sets;
+  struct View {
+    DevElOp E;
+    DevCsr A, P, PT;
+    double *Y, *v, *out, *elbuf, *x, *r, *d, *xc, *bc;
+  };
+  std::vector<View> vw;
+  Level* lc = has_coarse ? &level(l - 1) : nullptr;
+  vw.push_back(View{E0, m.A.view, has_coarse ? lc->mg->P.view : DevCsr(), has_coarse ? lc->mg->PT.view : DevCsr(), Y_.p, m.ev0.p,
+                    m.ev1.p, m.elbuf.p, m.x.p, m.r.p, m.d0.p, has_coarse ? lc->mg->x.p : nullptr, has_coarse ? lc->mg->b.p : nullptr});
+  for (int r = 1; r < nrot; ++r) {
+    auto q = std::make_unique<Set>();
+    auto dup = [&](DevBuf<double>& dst, const double* src, size_t cnt) {
+      dst.alloc(cnt);
+      if (cnt) hip_check(hipMemcpyAsync(dst.p, src, cnt * sizeof(double), hipMemcpyDeviceToDevice, ctx_.stream), "dup");
+    };
+    dup(q->Bvals, lv.B.view.vals, lv.B.view.nnz);
+    dup(q->Y, Y_.p, (size_t)n_ * nY);
+    dup(q->v, m.ev0.p, N);
+    q->out.alloc(N);
+    q->elbuf.alloc(m.elbuf.n);
+    dup(q->x, m.ev0.p, N);
+    dup(q->r, m.ev0.p, N);
+    dup(q->d, m.ev0.p, N);
+    dup(q->Avals, m.A.view.vals, m.A.view.nnz);
+    View V = vw[0];
+    V.E.vals = q->Bvals.p;
+    V.A.vals = q->Avals.p;
+    V.Y = q->Y.p;
+    V.v = q->v.p;
+    V.out = q->out.p;
+    V.elbuf = q->elbuf.p;
+    V.x = q->x.p;
+    V.r = q->r.p;
+    V.d = q->d.p;
+    if (has_coarse) {
+      q->P.upload(P_host_[l - 1]);
+      q->PT.upload(transpose(P_host_[l - 1]));
+      q->xc.alloc(lc->plan.N);
+      hip_check(hipMemsetAsync(q->xc.p, 0, q->xc.n * sizeof(double), ctx_.stream), "memset");
+      q->bc.alloc(lc->plan.N);
+      V.P = q->P.view;
+      V.PT = q->PT.view;
+      V.xc = q->xc.p;
+      V.bc = q->bc.p;
+    }
+    vw.push_back(V);
+    sets.push_back(std::move(q));
+  }
+  hipEvent_t e0, e1;
+  hip_check(hipEventCreate(&e0), "event");
+  hip_check(hipEventCreate(&e1), "event");
+  auto timeit = [&](auto&& fn) {
+    for (int r = 0; r < nrot; ++r) fn(vw[r]);
+    hip_check(hipEventRecord(e0, ctx_.stream), "rec");
+    for (int r = 0; r < reps; ++r) fn(vw[r % nrot]);
+    hip_check(hipEventRecord(e1, ctx_.stream), "rec");
+    hip_check(hipEventSynchronize(e1), "evsync");
+    float ms = 0;
+    hip_check(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+    return (double)ms / reps;
+  };
+  MgKernelTimes kt{};
+  kt.ms[0] = timeit([&](View& V) {
+    MgEpi e;
+    e.mode = MG_PLAIN;
+    e.n = N;
+    e.v = V.v;
+    e.out = V.out;
+    launch_elop_apply(ctx_.stream, V.E, P_, V.Y, V.elbuf, e);
+  });
+  kt.ms[1] = timeit([&](View& V) {
+    MgEpi e;
+    e.mode = MG_STEP;
+    e.n = N;
+    e.v = V.d;
+    e.x = V.x;
+    e.r = V.r;
+    e.dinv = m.dinv.p;
+    e.coef = m.coef.p;
+    e.has_next = 1;
+    e.k = 1;
+    e.d_new = V.out;
+    launch_elop_apply(ctx_.stream, V.E, P_, V.Y, V.elbuf, e);
+  });
+  kt.ms[2] = timeit([&](View& V) {
+    MgEpi e;
+    e.mode = MG_PLAIN;
+    e.n = N;
+    e.v = V.v;
+    e.out = V.out;
+    launch_csr_apply(ctx_.stream, V.A, e);
+  });
+  if (has_coarse) {
+    kt.ms[3] = timeit([&](View& V) { launch_spmv(ctx_.stream, V.P, V.xc, V.x, V.x); });
+    kt.ms[4] = timeit([&](View& V) { launch_spmv(ctx_.stream, V.PT, V.r, nullptr, V.bc); });
+  }
+  hip_check(hipStreamSynchronize(ctx_.stream), "sync");
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  const double nnzB = lv.B.view.nnz, nel = E0.nel, cm = E0.cmax;
+  // matrix-free H v: values once + column ids + class ids + Y + element results written and read + their gather lists + v, out
+  const double hv = nnzB * 8 + nel * cm * 4 + nel * 4 + (double)n_ * nY * 8 + nel * cm * (8 + 8 + 4) + (N + 1.0) * 4 + 2.0 * N * 8;
+  kt.bytes[0] = hv;
+  kt.bytes[1] = hv + 5.0 * N * 8;      // + x, r read and written, dinv read, d_new written (out counted in hv)
+  kt.bytes[2] = (double)m.A.view.nnz * 12 + (N + 1.0) * 4 + 2.0 * N * 8;
+  // "2 x apply_D-class passes + 3 vectors" on CSR operands
+  const double csrB = nnzB * 12 + ((double)lv.B.view.rows + 1) * 4, csrBT = nnzB * 12 + (N + 1.0) * 4;
+  kt.alg[0] = csrB + csrBT + (double)n_ * nY * 8 + 2.0 * N * 8;
+  kt.alg[1] = kt.alg[0] + 3.0 * N * 8;
+  kt.alg[2] = kt.bytes[2];
+  // the unfused sequence: Dz = B v (write n K), u = Y Dz (read n K + Y, write n K), g = B' u (read n K)
+  kt.bytes[5] = kt.alg[0] + 4.0 * n_ * P_.K * 8;
+  if (has_coarse) {
+    const DevCsr& Pv = lc->mg->P.view;
+    kt.bytes[3] = kt.alg[3] = (double)Pv.nnz * 12 + (Pv.rows + 1.0) * 4 + Pv.cols * 8.0 + Pv.rows * 16.0;
+    const DevCsr& PTv = lc->mg->PT.view;
+    kt.bytes[4] = kt.alg[4] = (double)PTv.nnz * 12 + (PTv.rows + 1.0) * 4 + PTv.cols * 8.0 + PTv.rows * 8.0;
+  }
+  return kt;
 }
 
 bool Amg::pcg_solve_linear(int l, const double* s_host, const double* g_host, double* x_host, int* iters, double* relres) {

@@ -31,10 +31,11 @@ compile "$HERE/_obj/mg.o" "$HERE/mg.hip" "$HIPCC" --offload-arch=gfx950 $CXXFLAG
 compile "$HERE/_obj/amg_mg.o" "$HERE/amg_mg.cpp" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS -x hip
 compile "$HERE/_obj/gpuchol.o" "$HERE/gpuchol.hip" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS
 compile "$HERE/_obj/amg.o" "$HERE/amg.cpp" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS -x hip
+compile "$HERE/_obj/comm.o" "$HERE/comm.cpp" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS -x hip
 compile "$HERE/_obj/capi.o" "$HERE/capi.cpp" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS -x hip
 for pid in "${pids[@]}"; do
   wait "$pid" || { echo "build.sh: a compile job failed" >&2; exit 1; }
 done
 rm -f "$OUT/libmgb_hip.so"
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libmgb_hip.so" "$HERE"/_obj/{geometry,mfchol,kernels,kernels_f32,mg,gpuchol,amg,amg_mg,capi}.o -lpthread
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libmgb_hip.so" "$HERE"/_obj/{geometry,mfchol,kernels,kernels_f32,mg,gpuchol,amg,amg_mg,comm,capi}.o -lpthread -ldl
 echo "built $OUT/libmgb_hip.so"

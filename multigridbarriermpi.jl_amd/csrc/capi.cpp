@@ -34,6 +34,7 @@ struct mgb_amg_s {
   bool schedule_all = false;
   bool host_solve = false;
   bool pcg = false;
+  bool upstream_stop = false;
 };
 struct mgb_plan_s {
   LevelPlan plan;
@@ -282,10 +283,23 @@ int mgb_ctx_synchronize(mgb_ctx ctx) {
 int mgb_ctx_set_comm(mgb_ctx ctx, int rank, int world, mgb_allreduce_fn fn, void* user) {
   return guard([&] {
     need(ctx && world >= 1 && rank >= 0 && rank < world && (world == 1 || fn), "ctx_set_comm: bad arguments");
+    ctx->ctx.drop_comm();
     ctx->ctx.rank = rank;
     ctx->ctx.world = world;
     ctx->ctx.allreduce = fn;
     ctx->ctx.allreduce_user = user;
+  });
+}
+int mgb_rccl_unique_id(char* out128) {
+  return guard([&] {
+    need(out128, "rccl_unique_id: null output");
+    rccl_unique_id(out128);
+  });
+}
+int mgb_ctx_set_comm_rccl(mgb_ctx ctx, const char* unique_id128, int rank, int world) {
+  return guard([&] {
+    need(ctx, "null ctx");
+    ctx->ctx.set_comm_rccl(unique_id128, rank, world);
   });
 }
 int mgb_ctx_comm_stats(mgb_ctx ctx, long long* calls, double* bytes) {
@@ -616,7 +630,8 @@ int mgb_axpy(mgb_vec x, double alpha, mgb_vec y, mgb_vec out) {
 int mgb_vec_allreduce_sum(mgb_vec x) {
   return guard([&] {
     need(x, "null argument");
-    x->ctx->ctx.allreduce_sum(x->buf.p, x->n);
+    x->ctx->ctx.allreduce_sum(x->buf.p, x->n, /*even_single=*/true);
+    hip_check(hipStreamSynchronize(x->ctx->ctx.stream), "sync allreduce");      // a library-owned communicator works on the stream
   });
 }
 int mgb_all_isfinite(mgb_vec x, int* out) {
@@ -849,7 +864,7 @@ int mgb_amg_set_solver(mgb_amg a, int solver) {
   });
 }
 int mgb_amg_set_pcg(mgb_amg a, double rtol, int maxit, int degree, int power_its, double lo_frac, double hi_frac, int chunk,
-                    int fallback, int assembled_top) {
+                    int fallback, int assembled_top, int giveup) {
   return guard([&] {
     need(a, "null amg");
     PcgOptions& o = a->amg->pcg_opt;
@@ -867,15 +882,17 @@ int mgb_amg_set_pcg(mgb_amg a, double rtol, int maxit, int degree, int power_its
     if (chunk > 0) o.chunk = chunk;
     if (fallback >= 0) o.fallback = fallback != 0;
     if (assembled_top >= 0) o.assembled_top = assembled_top != 0;
+    if (giveup >= 0) o.giveup = giveup;
   });
 }
-int mgb_amg_sol_pcg(mgb_amg a, long long* counts3, double* time_s) {
+int mgb_amg_sol_pcg(mgb_amg a, long long* counts4, double* time_s) {
   return guard([&] {
     need(a, "null amg");
-    if (counts3) {
-      counts3[0] = a->stats.pcg_solves;
-      counts3[1] = a->stats.pcg_iters;
-      counts3[2] = a->stats.pcg_fallbacks;
+    if (counts4) {
+      counts4[0] = a->stats.pcg_solves;
+      counts4[1] = a->stats.pcg_iters;
+      counts4[2] = a->stats.pcg_fallbacks;
+      counts4[3] = a->stats.pcg_gaveup_at;
     }
     if (time_s) *time_s = a->stats.time_pcg;
   });
@@ -926,10 +943,26 @@ int mgb_amg_pcg_solve_linear(mgb_amg a, int level, const double* s, const double
     if (converged) *converged = ok ? 1 : 0;
   });
 }
+int mgb_amg_time_mg_kernels(mgb_amg a, int level, int reps, int nrot, double* ms6, double* bytes6, double* alg6) {
+  return guard([&] {
+    need(a && ms6 && bytes6 && alg6 && reps > 0 && nrot >= 1 && nrot <= 64 && level >= 0 && level < a->amg->L(),
+         "time_mg_kernels: bad arguments");
+    Amg::MgKernelTimes k = a->amg->time_mg_kernels(level, reps, nrot);
+    std::copy(k.ms, k.ms + 6, ms6);
+    std::copy(k.bytes, k.bytes + 6, bytes6);
+    std::copy(k.alg, k.alg + 6, alg6);
+  });
+}
 int mgb_amg_mg_info(mgb_amg a, int top, int* coarsest) {
   return guard([&] {
     need(a && top >= 0 && top < a->amg->L(), "mg_info: bad arguments");
     if (coarsest) *coarsest = a->amg->mg_coarsest(top);
+  });
+}
+int mgb_amg_set_stop_rule(mgb_amg a, int upstream) {
+  return guard([&] {
+    need(a, "null amg");
+    a->upstream_stop = upstream != 0;
   });
 }
 int mgb_amg_set_schedule(mgb_amg a, int all_levels) {
@@ -945,6 +978,7 @@ int mgb_amg_solve(mgb_amg a, double tol, double t0, double kappa, int maxit, int
     o.schedule_all = a->schedule_all;
     o.host_solve = a->host_solve;
     o.pcg = a->pcg;
+    o.upstream_stop = a->upstream_stop;
     if (tol > 0) o.tol = tol;
     if (t0 > 0) o.t0 = t0;
     if (kappa > 1) o.kappa = kappa;

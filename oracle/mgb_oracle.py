@@ -755,10 +755,17 @@ def amgb_step(B: Barrier, M: AMG, z, Dz0, c, maxit, lam_tol, log=None, schedule=
     return dict(z=z, Dz0=Dz0, its=its, converged=converged)
 
 
+STOP_RULE = "fixed"      # "fixed": the continuation ends at t_stop (below); "upstream": the literal `while t <= 1/tol`, t <- kappa t
+
+
 def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max_newton=None, log=None,
-              schedule=None, early_stop=None):
+              schedule=None, early_stop=None, stop_rule=None):
     """`early_stop(Dz0) -> bool` is evaluated after every centering (feasibility phase: stop as soon as the
-    original cone is strictly satisfied)."""
+    original cone is strictly satisfied).  `stop_rule`: see STOP_RULE; both rules are [UPSTREAM-UNVERIFIED] (SURVEY.md
+    Appendix A recalls `t <- kappa t until t > 1/tol`); they visit the same ts whenever kappa is never reduced."""
+    stop_rule = STOP_RULE if stop_rule is None else stop_rule
+    if stop_rule not in ("fixed", "upstream"):
+        raise ValueError("stop_rule must be 'fixed' or 'upstream'")
     if max_newton is None:
         max_newton = int(math.ceil(math.log2(-math.log2(np.finfo(np.float64).eps)))) + 2 + 40
     lam_tol = math.sqrt(float(np.min(M.w))) / 2
@@ -787,14 +794,17 @@ def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max
     # The continuation ends at a FIXED barrier parameter: t_stop = the first value of the nominal sequence t0 * kappa0^k beyond
     # 1 / tol (1e8 for the defaults).  Without it the last t depends on the history of kappa reductions -- a discrete, rounding
     # sensitive path -- and two correct runs end at different central points (fem2d L=7, p=1: t = 1.0e8 or 1.8e8, z 1e-6 apart).
+    # stop_rule = "upstream" keeps the literal loop: continue while t <= 1 / tol, every step t <- kappa t.
     t_stop = t
     while t_stop <= 1 / tol:
         t_stop *= kappa0
-    while t < t_stop and kappa > 1 and k < maxit and not stopped:
+    fixed = stop_rule == "fixed"
+    going = (lambda tt: tt < t_stop) if fixed else (lambda tt: tt <= 1 / tol)
+    while going(t) and kappa > 1 and k < maxit and not stopped:
         k += 1
         it_k = np.zeros(len(M.R), dtype=np.int64)
         while kappa > 1:
-            t1 = min(kappa * t, t_stop)
+            t1 = min(kappa * t, t_stop) if fixed else kappa * t
             SOL = amgb_step(B, M, z, Dz0, t1 * c, max_newton, lam_tol, log, schedule)
             it_k += SOL["its"]
             if SOL["converged"]:
@@ -807,7 +817,7 @@ def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max
                 kappa = 1.0
         its.append(it_k); ts.append(t); cdots.append(cdot(Dz0))
         stopped = early_stop is not None and early_stop(Dz0)
-    if t < t_stop and not stopped:
+    if going(t) and not stopped:
         raise RuntimeError("amgb: convergence failure at t=%g kappa=%g" % (t, kappa))
     return dict(z=z, its=np.array(its).T, ts=np.array(ts), c_dot_Dz=np.array(cdots),
                 t_elapsed=time.time() - t_begin)
@@ -825,7 +835,7 @@ class AMGBSOL:
 
 def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=None, g=None,
          tol=None, t=0.1, maxit=10000, kappa=10.0, verbose=False, logfile=None, keep_log=False,
-         schedule=None, extra=(), cone_idx=None) -> AMGBSOL:
+         schedule=None, extra=(), cone_idx=None, stop_rule=None) -> AMGBSOL:
     """`extra`: further convex sets intersected with the p-Laplace power cone (upstream `intersect`), e.g. LinearBarrier;
     `cone_idx`: the rows (q.., s) of D the power cone acts on (default: the last dim + 1 rows)."""
     dim = geometry.discretization["dim"]
@@ -848,7 +858,7 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
         zvec, SOL_feas = amgb_phase1_slack(geometry, state_variables, M.Dspec, Q, extra, zvec, Dz, tol, schedule, c=c)
     elif not np.all(np.isfinite(Q.F(x, Dz))):
         zvec, SOL_feas = amgb_phase1(geometry, state_variables, M.Dspec, Q, zvec, Dz, tol, schedule)
-    SOL = amgb_core(B, M, zvec, c, tol, t=t, maxit=maxit, kappa=kappa, log=log, schedule=schedule)
+    SOL = amgb_core(B, M, zvec, c, tol, t=t, maxit=maxit, kappa=kappa, log=log, schedule=schedule, stop_rule=stop_rule)
     z = SOL.pop("z").reshape(z0.shape, order="F")
     return AMGBSOL(z, SOL_feas, SOL, log or [], geometry)
 

@@ -87,7 +87,7 @@ def test_prolongation_nests_the_levels(M, kind, L):
         assert rel(A.restrict(l, rf), P.T @ rf) < 1e-13
 
 
-def _cheb_numpy(H, b, x, lam, degree, sweeps, lo_frac=0.1, hi_frac=1.1):
+def _cheb_numpy(H, b, x, lam, degree, sweeps, lo_frac=0.12, hi_frac=1.2):
     """Chebyshev iteration for the Jacobi-preconditioned system (Saad, Iterative Methods, Alg. 12.1) on [lo, hi] * lam:
     the recurrence csrc/mg.hip runs, `degree` applications of H per sweep."""
     dinv = 1.0 / H.diagonal()
@@ -132,7 +132,7 @@ def test_smoother_matches_numpy_restatement(M, kind, L, p, l, matrix_free):
     # the device's own estimate of lambda_max(Dinv H): power steps in the D inner product never overshoot
     x0 = np.zeros(N)
     _, est = A.smooth(l, sg, bg, x0, degree=2, sweeps=1, lmax=0.0, matrix_free=matrix_free)
-    assert 0.6 * lam <= est <= lam * (1 + 1e-10)
+    assert 0.9 * lam <= est <= lam * (1 + 1e-10)
     # and the smoother smooths: the error of a rough vector shrinks in the energy norm
     xs = spla.spsolve(H.tocsc(), bo)
     e0 = -xs

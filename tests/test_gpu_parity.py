@@ -788,3 +788,24 @@ def test_end_point_does_not_depend_on_summation_order(M):
     # two panels per launch (front_step2) against one: the same factorisation bit for bit, hence the same solve
     one = [ln for ln in rows if ln.startswith("one_panel_steps")]
     assert len(one) == 1 and float(one[0].rsplit("=", 1)[1]) == 0.0, one
+
+
+@pytest.mark.parametrize("kind,L,p", [("fem1d", 3, 2.0), ("fem2d", 3, 1.5)])
+def test_stop_rules_visit_the_nominal_sequence(M, kind, L, p):
+    """ADVICE r2 (mgb_amg_set_stop_rule): "upstream" = the literal `while t <= 1/tol: t <- kappa t`, "fixed" = end at the first
+    t0 kappa^k beyond 1/tol.  Without a kappa reduction both give ts = t0 kappa^k exactly (SOL_main.ts is an observable of the
+    reference, docs/src/api.md:97-101) and the same z, and the product follows the oracle under either rule."""
+    tol = np.sqrt(np.finfo(np.float64).eps)
+    want = [0.1]
+    while want[-1] <= 1 / tol:
+        want.append(want[-1] * 10.0)
+    zs = {}
+    for rule in ("fixed", "upstream"):
+        sol = getattr(M, kind + "_mpi_solve")(L=L, p=p, stop_rule=rule)
+        assert np.array_equal(sol.SOL_main["ts"], np.array(want)), rule
+        zs[rule] = M.mpi_to_native(sol).z
+        zo = getattr(O, kind + "_solve")(L=L, p=p, stop_rule=rule).z
+        assert rel(zs[rule], zo) < ZTOL
+    assert np.array_equal(zs["fixed"], zs["upstream"])
+    with pytest.raises(ValueError):
+        M.fem1d_mpi_solve(L=2, stop_rule="sometimes")

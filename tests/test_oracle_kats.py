@@ -251,3 +251,20 @@ def test_oracle_general_feasibility_phase():
     assert np.all(sol.z[:, 1] > np.abs(q) ** 1.5)
     with pytest.raises(RuntimeError):
         O.amgb(g, p=1.5, f=f, g=gg, extra=[O.LinearBarrier([0], [1.0], -5.0)])
+
+
+def test_both_continuation_stop_rules_visit_the_nominal_sequence():
+    """the end of the t-continuation is selectable (oracle STOP_RULE / mgb_amg_set_stop_rule): "upstream" = the
+    literal `while t <= 1/tol: t <- kappa t`, "fixed" = stop at the first t0 kappa^k beyond 1/tol.
+    SOL_main.ts is an observable of the reference (docs/src/api.md:97-101); when kappa is never reduced both rules must give
+    exactly ts = t0 kappa^k, k = 0 .. with the last one the first beyond 1/tol, and the same z."""
+    sols = {r: O.amgb(O.fem1d(3), p=2.0, stop_rule=r) for r in ("fixed", "upstream")}
+    tol = np.sqrt(np.finfo(np.float64).eps)
+    want = [0.1]
+    while want[-1] <= 1 / tol:
+        want.append(want[-1] * 10.0)
+    for r, s in sols.items():
+        assert np.array_equal(s.SOL_main["ts"], np.array(want)), r
+    assert np.array_equal(sols["fixed"].z, sols["upstream"].z)
+    with pytest.raises(ValueError):
+        O.amgb(O.fem1d(2), stop_rule="sometimes")

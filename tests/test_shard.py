@@ -239,6 +239,32 @@ def test_rccl_allreduce_callback_on_a_raw_device_pointer(gpu_required):
     assert out[0][1] == 999 * 1000 / 2
 
 
+def _lib_rccl_worker(rank, world, port, q):
+    os.environ.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import mgb_amd as M
+    from mgb_amd import _lib
+    be = M.HPCBackend(0)
+    be.set_comm_rccl(0, 1, M.rccl_unique_id())      # ncclCommInitRank inside the library, no torch in this process
+    v = M.HPCVector(np.arange(1000.0), be)
+    _lib.call("mgb_vec_allreduce_sum", v.handle)    # ncclAllReduce on the context stream
+    st = be.comm_stats()
+    # a full solve on a context that carries the communicator (world 1: the Newton loop itself never reduces)
+    sol = M.fem2d_mpi_solve(L=2, p=1.5, backend=be)
+    q.put((rank, float(v.to_numpy().sum()), st["calls"], st["bytes"], float(np.linalg.norm(M.mpi_to_native(sol).z))))
+
+
+@pytest.mark.gpu
+def test_library_owned_rccl_communicator_one_rank(gpu_required):
+    """mgb_rccl_unique_id / mgb_ctx_set_comm_rccl: the communicator lives in the library (the reference's collectives are
+    in-library too, src:125,132) and the collective is an ncclAllReduce enqueued on the context stream.  The test box has
+    one GPU and RCCL refuses two ranks on one device, so the world has one rank: what is exercised is librccl's run-time
+    binding, ncclCommInitRank, the stream-ordered collective and the teardown."""
+    out = _run(_lib_rccl_worker, 1)
+    assert out[0][1] == 999 * 1000 / 2 and out[0][2] == 1 and out[0][3] == 8000.0 and out[0][4] > 0
+
+
 def test_plan_shards_sum_to_the_full_plan_gloo_world3_uneven():
     """Three ranks: 8 / 32 elements do not divide evenly, the row blocks differ in size and still partition."""
     out = _run(_shard_worker, 3)

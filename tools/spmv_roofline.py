@@ -42,6 +42,19 @@ def probe(L, p=1.0, reps=24, nrot=None):
         gbs = v["bytes"] / max(v["ms"], 1e-9) / 1e6
         out["kernels"][k] = dict(us=1e3 * v["ms"], MB=v["bytes"] / 1e6, GBs=gbs, frac_hbm=gbs / HBM_PEAK_GBS,
                                  rotating_working_set_MB=nrot * v["bytes"] / 1e6)
+    # multigrid kernels of the same level: matrix-free H v, one Chebyshev step, transfers.
+    # frac_hbm: the CSR-based algorithmic bytes SURVEY.md section 8(d) prescribes / time; frac_hbm_moved: what the kernel moves by
+    # construction (values once for both halves, 1-byte local columns from cache-resident class tables) / time
+    nrot_mg = 1 if L <= 7 else int(min(8, max(2, -(-2 * INFINITY_CACHE_BYTES // max(1, n * 200)))))
+    out["mg_rotating_copies"] = nrot_mg
+    out["mg_kernels"] = {}
+    for k, v in A.time_mg_kernels(A.L - 1, reps, nrot_mg).items():
+        if v["ms"] <= 0:
+            out["mg_kernels"][k] = dict(MB=v["bytes"] / 1e6)
+            continue
+        out["mg_kernels"][k] = dict(us=1e3 * v["ms"], MB_moved=v["bytes"] / 1e6, MB_algorithmic=v["algorithmic_bytes"] / 1e6,
+                                    frac_hbm=v["algorithmic_bytes"] / v["ms"] / 1e6 / HBM_PEAK_GBS,
+                                    frac_hbm_moved=v["bytes"] / v["ms"] / 1e6 / HBM_PEAK_GBS)
     return out
 
 
