@@ -123,10 +123,10 @@ struct DevElCsrOwned {
 struct DevElOpOwned {
   DevElOp view;
   DevBuf<int> ecols, cls, dptr, didx;
-  DevBuf<unsigned short> c_rowptr, c_tptr, c_tk, c_trow;
-  DevBuf<unsigned char> c_lcol;
+  DevBuf<unsigned short> c_rowptr, c_tptr;
+  DevBuf<unsigned long long> c_ent;
   // block = nodes per element, K = rows of D: rows [e block K, (e + 1) block K) of B form element e
-  bool build(const Csr& B, const DevCsr& Bdev, int block, int K);
+  bool build(const Csr& B, const DevCsr& Bdev, int block, int K, int nY);
 };
 
 // Host-side symbolic pieces of the multigrid hierarchy (testable without a GPU)

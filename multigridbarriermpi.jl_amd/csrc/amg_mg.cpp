@@ -23,7 +23,7 @@ static double now_s() {
 
 // ------------------------------------------------------------------ host symbolic pieces
 
-bool DevElOpOwned::build(const Csr& B, const DevCsr& Bdev, int block, int K) {
+bool DevElOpOwned::build(const Csr& B, const DevCsr& Bdev, int block, int K, int nY) {
   view = DevElOp();
   const int rpe = block * K;
   if (block < 1 || K < 1 || K > 8 || rpe > 65535 || B.rows == 0 || B.rows % rpe) return false;
@@ -39,15 +39,19 @@ bool DevElOpOwned::build(const Csr& B, const DevCsr& Bdev, int block, int K) {
     cmax = std::max(cmax, (int)c.size());
   }
   if (cmax < 1 || cmax > 255 || nzm > 65535) return false;
-  // elements per workgroup pass: ~512 rows, staging buffers within 60 KiB of LDS
-  int epb = std::max(1, std::min(64, 512 / rpe));
-  while (epb > 1 && (size_t)epb * (cmax + nzm + rpe) * 8 > 60 * 1024) --epb;
-  if ((size_t)epb * (cmax + nzm + rpe) * 8 > 60 * 1024) return false;
+  // threads per element: the smallest power of two covering its rows (8 .. 256); LDS per element: xs, vs, ds, us, ys (doubles)
+  // + rowptr / tptr / tk / trow (16 bit) + lcol (8 bit) of its class, padded to doubles
+  int tpe = 8;
+  while (tpe < 256 && tpe < rpe) tpe <<= 1;
+  const int table_bytes = 2 * (rpe + 1) + 2 * (cmax + 1);
+  const int slot_doubles = cmax + 3 * nzm + 2 * rpe + block * nY + (table_bytes + 7) / 8;      // xs, vs, pr, ent, ds, us, ys, rp, tp
+  while (tpe < 256 && (size_t)(256 / tpe) * slot_doubles * 8 > 60 * 1024) tpe <<= 1;      // fewer elements per pass
+  if ((size_t)(256 / tpe) * slot_doubles * 8 > 60 * 1024) return false;
   // structure classes: (relative row offsets, local columns) -> class id
   std::map<std::string, int> ids;
   std::vector<int> cls(nel);
-  std::vector<unsigned short> c_rowptr, c_tptr, c_tk, c_trow;
-  std::vector<unsigned char> c_lcol;
+  std::vector<unsigned short> c_rowptr, c_tptr;
+  std::vector<unsigned long long> c_ent;
   std::vector<int> ec((size_t)nel * cmax);
   std::string key;
   std::vector<unsigned char> lc;
@@ -67,12 +71,10 @@ bool DevElOpOwned::build(const Csr& B, const DevCsr& Bdev, int block, int K) {
       const int id = (int)ids.size();
       it = ids.emplace(key, id).first;
       c_rowptr.resize((size_t)(id + 1) * (rpe + 1));
-      c_lcol.resize((size_t)(id + 1) * nzm, 0);
       c_tptr.resize((size_t)(id + 1) * (cmax + 1));
-      c_tk.resize((size_t)(id + 1) * nzm, 0);
-      c_trow.resize((size_t)(id + 1) * nzm, 0);
+      c_ent.resize((size_t)(id + 1) * nzm, 0ull);
       for (int r = 0; r <= rpe; ++r) c_rowptr[(size_t)id * (rpe + 1) + r] = (unsigned short)(B.rowptr[e * rpe + r] - k0);
-      std::copy(lc.begin(), lc.end(), c_lcol.begin() + (size_t)id * nzm);
+      for (size_t k = 0; k < lc.size(); ++k) c_ent[(size_t)id * nzm + k] |= (unsigned long long)lc[k] << 32;
       // column-wise traversal: rows ascending within a column (a node's K rows are consecutive)
       std::vector<int> cnt(cmax + 1, 0);
       for (unsigned char j : lc) cnt[j + 1]++;
@@ -82,8 +84,7 @@ bool DevElOpOwned::build(const Csr& B, const DevCsr& Bdev, int block, int K) {
       for (int r = 0; r < rpe; ++r)
         for (int k = B.rowptr[e * rpe + r] - k0; k < B.rowptr[e * rpe + r + 1] - k0; ++k) {
           const int pp = pos[lc[k]]++;
-          c_tk[(size_t)id * nzm + pp] = (unsigned short)k;
-          c_trow[(size_t)id * nzm + pp] = (unsigned short)r;
+          c_ent[(size_t)id * nzm + pp] |= (unsigned long long)(unsigned short)k | (unsigned long long)(unsigned short)r << 16;
         }
     }
     cls[e] = it->second;
@@ -105,10 +106,8 @@ bool DevElOpOwned::build(const Csr& B, const DevCsr& Bdev, int block, int K) {
   this->dptr.upload(dptr.data(), dptr.size());
   this->didx.upload(didx.data(), didx.size());
   this->c_rowptr.upload(c_rowptr.data(), c_rowptr.size());
-  this->c_lcol.upload(c_lcol.data(), c_lcol.size());
   this->c_tptr.upload(c_tptr.data(), c_tptr.size());
-  this->c_tk.upload(c_tk.data(), c_tk.size());
-  this->c_trow.upload(c_trow.data(), c_trow.size());
+  this->c_ent.upload(c_ent.data(), c_ent.size());
   view.nel = nel;
   view.rows_per_el = rpe;
   view.cmax = cmax;
@@ -117,16 +116,15 @@ bool DevElOpOwned::build(const Csr& B, const DevCsr& Bdev, int block, int K) {
   view.nnz_max = nzm;
   view.ncls = (int)ids.size();
   view.N = N;
-  view.epb = epb;
+  view.tpe = tpe;
+  view.slot_doubles = slot_doubles;
   view.ecols = this->ecols.p;
   view.cls = this->cls.p;
   view.rowptr = Bdev.rowptr;
   view.vals = Bdev.vals;
   view.c_rowptr = this->c_rowptr.p;
-  view.c_lcol = this->c_lcol.p;
   view.c_tptr = this->c_tptr.p;
-  view.c_tk = this->c_tk.p;
-  view.c_trow = this->c_trow.p;
+  view.c_ent = this->c_ent.p;
   view.dptr = this->dptr.p;
   view.didx = this->didx.p;
   return true;
@@ -249,7 +247,7 @@ bool Amg::mg_ensure_elop(Level& lv) {
   Level::Mg& m = mg_of(lv);
   if (!m.elop_tried) {
     m.elop_tried = true;
-    if (geo_.block >= 1 && n_ % geo_.block == 0 && m.elop.build(lv.plan.B, lv.B.view, geo_.block, P_.K))
+    if (geo_.block >= 1 && n_ % geo_.block == 0 && m.elop.build(lv.plan.B, lv.B.view, geo_.block, P_.K, P_.nY()))
       m.elbuf.alloc((size_t)m.elop.view.nel * m.elop.view.cmax);
   }
   return m.elop.view.valid();

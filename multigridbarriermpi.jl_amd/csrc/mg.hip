@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 #include "devutil.hpp"
 
@@ -20,146 +21,199 @@ namespace {
 
 __device__ inline bool mg_done(const double* done) { return done && *done != 0.0; }
 
-// u = Y_q d over the active columns of every barrier term (Y: packed upper triangles per term, barrier_f2_kernel's slots);
-// d is overwritten in place (K <= 8 values held in registers first)
-__device__ inline void apply_Y_node(const BarrierParams& P, const double* __restrict__ yq, double* d) {
-  double in[8], out[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    in[j] = j < P.K ? d[j] : 0.0;
-    out[j] = 0.0;
-  }
-  int slot = 0;
-  for (int ci = 0; ci < P.ncones; ++ci) {
-    const ConeSpec& S = P.cone[ci];
-    const int nact = S.nact();
-    for (int a = 0; a < nact; ++a) {
-      const int ra = S.col(a);
-      for (int b = a; b < nact; ++b, ++slot) {
-        const int rb = S.col(b);
-        const double y = yq[slot];
-        // run-time row indices: unrolled selects keep in / out in registers
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          double add = 0.0;
-          if (j == ra) {
-            double o = 0.0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o = (i == rb) ? in[i] : o;
-            add += y * o;
-          }
-          if (j == rb && ra != rb) {
-            double o = 0.0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o = (i == ra) ? in[i] : o;
-            add += y * o;
-          }
-          out[j] += add;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-    if (j < P.K) d[j] = out[j];
-}
+// Per D-row a: the (b, slot) pairs with a nonzero d2F / dDz_a dDz_b, over all barrier terms (barrier_f2_kernel's packed upper
+// triangles, mirrored): u_a = sum over a's pairs of Y[slot] d_b.  Uniform over the nodes.
+struct YList {
+  unsigned char ptr[9];
+  unsigned short pair[8 * 8 * kMaxCones];      // b | slot << 8
+};
 
-// Phase 1 of the matrix-free product.  A workgroup takes E.epb consecutive elements per pass:
-//   A  xs  <- vin at the elements' columns (one coalesced index read + one gather per element column)
-//   B  vs  <- the elements' nonzero values (contiguous in B's CSR: one coalesced stream, read once for both halves)
-//   C  ds  <- B_e xs          (one thread per row; offsets / local columns from the class table)
-//   D  ds  <- Y_q ds          (one thread per node; the K x K block applied in registers)
-//   E  elbuf <- B_e' ds       (one thread per element column, column-wise traversal from the class table: fixed order)
-// diag != 0: phase E forms diag(B_e' Y_e B_e) instead (pairs of a column's entries that sit on the same node).
-__global__ __launch_bounds__(kBlock) void elop_apply_kernel(DevElOp E, BarrierParams P, const double* __restrict__ Y,
+// Phase 1 of the matrix-free product.  TPE threads work on one element, kBlock / TPE elements per pass; everything an element
+// needs is staged in LDS by ONE round of independent, coalesced loads (class id -> its structure table, column ids -> vin,
+// nonzero values, Y), then LDS-only phases:
+//   C   ds <- B_e xs           lane = row
+//   D   us <- Y_q ds           lane = row (node q, D-row a) through the pair list of a
+//   E1  pr <- B_e(k) us        lane = nonzero, in column-wise order (balanced whatever the column lengths are)
+//   E2  elbuf <- column sums   lane = element column; rows ascending within a column: fixed order, reproducible
+// diag != 0: E forms diag(B_e' Y_e B_e) instead.
+// Class table entry per nonzero (64 bit): bits 0-15 local nonzero index and 16-31 local row of the p-th entry in column-wise
+// order, bits 32-39 local column of the k-th entry in row-wise order.
+constexpr int kPre = 4;      // register prefetch depth per lane (values / table-free data of the NEXT pass); deeper elements take the plain path
+
+template <int TPE>
+__global__ __launch_bounds__(kBlock) void elop_apply_kernel(DevElOp E, int K, int nY, YList yl, const double* __restrict__ Y,
                                                              const double* __restrict__ v, const double* __restrict__ vmul,
                                                              const double* __restrict__ vscale, double* __restrict__ elbuf,
                                                              int diag, const double* done) {
   if (mg_done(done)) return;
   extern __shared__ double lds_el[];
-  const int rpe = E.rows_per_el, cmax = E.cmax, nzm = E.nnz_max, K = E.K, nY = P.nY();
-  double* xs = lds_el;
-  double* vs = xs + (size_t)E.epb * cmax;
-  double* ds = vs + (size_t)E.epb * nzm;
+  __shared__ YList yls;
+  constexpr int EPB = kBlock / TPE;
+  const int rpe = E.rows_per_el, cmax = E.cmax, nzm = E.nnz_max, blk = E.block;
+  const int el = threadIdx.x / TPE, ln = threadIdx.x % TPE;
+  if (threadIdx.x < 9) yls.ptr[threadIdx.x] = yl.ptr[threadIdx.x];
+  for (int i = threadIdx.x; i < 8 * 8 * kMaxCones; i += kBlock) yls.pair[i] = yl.pair[i];
+  // this element's LDS slot
+  double* base = lds_el + (size_t)el * E.slot_doubles;
+  double* xs = base;
+  double* vs = xs + cmax;
+  double* ds = vs + nzm;
+  double* us = ds + rpe;
+  double* ys = us + rpe;
+  double* pr = ys + (size_t)blk * nY;
+  unsigned long long* ent = reinterpret_cast<unsigned long long*>(pr + nzm);
+  unsigned short* rp = reinterpret_cast<unsigned short*>(ent + nzm);
+  unsigned short* tp = rp + (rpe + 1);
+  const unsigned char* entb = reinterpret_cast<const unsigned char*>(ent);
+  const unsigned* entw = reinterpret_cast<const unsigned*>(ent);
   const double vsc = vscale ? *vscale : 1.0;
-  const int npass = (E.nel + E.epb - 1) / E.epb;
-  for (int ps = xcd_block(blockIdx.x, gridDim.x); ps < npass; ps += gridDim.x) {
-    const int e0 = ps * E.epb, ne = min(E.epb, E.nel - e0);
+  const int npass = (E.nel + EPB - 1) / EPB;
+  const int nYel = blk * nY;
+  // Software pipeline: the HBM-latency loads of pass n + 1 (nonzero values, Y, column ids, class, extent) are issued into
+  // registers before the LDS-only phases of pass n and land in LDS at the top of pass n + 1; only the gather of vin (its column
+  // ids are already in registers) and a class table that changed are fetched inside the pass.
+  const bool pipelined = (nzm + TPE - 1) / TPE <= kPre && (nYel + TPE - 1) / TPE <= kPre && (cmax + TPE - 1) / TPE <= kPre;
+  double pv[kPre], py[kPre];
+  int pcol[kPre], pc = 0, pk0 = 0, pnz = 1, pe = 0;      // stage B (next pass): values, Y, column ids
+  int qc = 0, qk0 = 0, qnz = 1, qe = 0;                   // stage A (the pass after): class and extent, which stage B's addresses need
+  // both stages load unconditionally at clamped (always valid) addresses -- a condition per load makes the compiler branch
+  // around it and wait for each one in turn; passes beyond the end recompute the last element and never store
+  auto stage_a = [&](int ps) {
+    qe = min(ps * EPB + el, E.nel - 1);
+    qc = E.cls[qe];
+    qk0 = E.rowptr[(size_t)qe * rpe];
+    qnz = E.rowptr[(size_t)(qe + 1) * rpe] - qk0;
+  };
+  auto stage_b = [&]() {
+    pe = qe;
+    pc = qc;
+    pk0 = qk0;
+    pnz = qnz;
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) pcol[u] = E.ecols[(size_t)pe * cmax + min(ln + u * TPE, cmax - 1)];
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) pv[u] = E.vals[pk0 + min(ln + u * TPE, pnz - 1)];
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) py[u] = Y[(size_t)pe * nYel + min(ln + u * TPE, nYel - 1)];
+  };
+  int have_cls = -1;      // class whose table this element slot holds: neighbouring elements mostly share it, so it is loaded once
+  int ps = xcd_block(blockIdx.x, gridDim.x);
+  if (pipelined && ps < npass) {
+    stage_a(ps);
+    stage_b();
+    stage_a(ps + gridDim.x);
+  }
+  for (; ps < npass; ps += gridDim.x) {
+    const int e = ps * EPB + el;
+    bool live = e < E.nel;
+    int nz = 0;
     __syncthreads();      // the previous pass is done with the staging buffers
-    if (!diag)
-      for (int idx = threadIdx.x; idx < ne * cmax; idx += kBlock) {
-        const int j = E.ecols[(size_t)e0 * cmax + idx];
-        double x = v[j];
-        if (vmul) x *= vmul[j];
-        xs[idx] = vsc * x;
+    if (pipelined) {
+      nz = pnz;
+      const int c = pc;
+      double xg[kPre];
+#pragma unroll
+      for (int u = 0; u < kPre; ++u) xg[u] = diag ? 0.0 : v[pcol[u]];
+      if (vmul && !diag) {
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) xg[u] *= vmul[pcol[u]];
       }
-    for (int idx = threadIdx.x; idx < ne * nzm; idx += kBlock) {
-      const int el = idx / nzm, kk = idx - el * nzm;
-      const int k0 = E.rowptr[(size_t)(e0 + el) * rpe], k1 = E.rowptr[(size_t)(e0 + el + 1) * rpe];
-      vs[idx] = kk < k1 - k0 ? E.vals[k0 + kk] : 0.0;
+#pragma unroll
+      for (int u = 0; u < kPre; ++u) {
+        const int k = ln + u * TPE;
+        if (k < nz) vs[k] = pv[u];
+        if (k < nYel) ys[k] = py[u];
+      }
+      // the next pass's loads go out before this pass's arithmetic (their class / extent arrived during the previous pass)
+      stage_b();
+      stage_a(ps + 2 * gridDim.x);
+#pragma unroll
+      for (int u = 0; u < kPre; ++u) {
+        const int j = ln + u * TPE;
+        if (j < cmax) xs[j] = vsc * xg[u];
+      }
+      if (c != have_cls) {      // uniform over the element's lanes; rare: neighbouring elements share their class
+        for (int i = ln; i <= rpe; i += TPE) rp[i] = E.c_rowptr[(size_t)c * (rpe + 1) + i];
+        for (int i = ln; i <= cmax; i += TPE) tp[i] = E.c_tptr[(size_t)c * (cmax + 1) + i];
+        for (int i = ln; i < nz; i += TPE) ent[i] = E.c_ent[(size_t)c * nzm + i];
+        have_cls = c;
+      }
+    } else if (live) {
+      const int c = E.cls[e];
+      const int k0 = E.rowptr[(size_t)e * rpe];
+      nz = E.rowptr[(size_t)(e + 1) * rpe] - k0;
+      if (!diag)
+        for (int j = ln; j < cmax; j += TPE) {
+          const int col = E.ecols[(size_t)e * cmax + j];
+          double x = v[col];
+          if (vmul) x *= vmul[col];
+          xs[j] = vsc * x;
+        }
+      for (int k = ln; k < nz; k += TPE) vs[k] = E.vals[k0 + k];
+      for (int i = ln; i < nYel; i += TPE) ys[i] = Y[(size_t)e * nYel + i];
+      if (c != have_cls) {      // uniform over the element's lanes
+        for (int i = ln; i <= rpe; i += TPE) rp[i] = E.c_rowptr[(size_t)c * (rpe + 1) + i];
+        for (int i = ln; i <= cmax; i += TPE) tp[i] = E.c_tptr[(size_t)c * (cmax + 1) + i];
+        for (int i = ln; i < nz; i += TPE) ent[i] = E.c_ent[(size_t)c * nzm + i];
+        have_cls = c;
+      }
     }
     __syncthreads();
     if (!diag) {
-      for (int idx = threadIdx.x; idx < ne * rpe; idx += kBlock) {
-        const int el = idx / rpe, rr = idx - el * rpe;
-        const int c = E.cls[e0 + el];
-        const unsigned short* rp = E.c_rowptr + (size_t)c * (rpe + 1);
-        const unsigned char* lc = E.c_lcol + (size_t)c * nzm;
-        const double* ve = vs + (size_t)el * nzm;
-        const double* xe = xs + (size_t)el * cmax;
-        double acc = 0.0;
-        for (int k = rp[rr]; k < rp[rr + 1]; ++k) acc += ve[k] * xe[lc[k]];
-        ds[idx] = acc;
-      }
-      __syncthreads();
-      for (int idx = threadIdx.x; idx < ne * E.block; idx += kBlock) {
-        const long long q = (long long)e0 * E.block + idx;
-        apply_Y_node(P, Y + q * nY, ds + (size_t)idx * K);      // node idx of the pass owns ds[idx * K .. + K)
-      }
-      __syncthreads();
-      for (int idx = threadIdx.x; idx < ne * cmax; idx += kBlock) {
-        const int el = idx / cmax, j = idx - el * cmax;
-        const int c = E.cls[e0 + el];
-        const unsigned short* tp = E.c_tptr + (size_t)c * (cmax + 1);
-        const unsigned short* tk = E.c_tk + (size_t)c * nzm;
-        const unsigned short* tr = E.c_trow + (size_t)c * nzm;
-        const double* ve = vs + (size_t)el * nzm;
-        const double* de = ds + (size_t)el * rpe;
-        double acc = 0.0;
-        for (int p = tp[j]; p < tp[j + 1]; ++p) acc += ve[tk[p]] * de[tr[p]];
-        elbuf[(size_t)e0 * cmax + idx] = acc;
-      }
-    } else {
-      // diagonal entry of column j: sum over nodes q of  b_q' Y_q b_q  with b_q = the column's entries on node q's K rows
-      for (int idx = threadIdx.x; idx < ne * cmax; idx += kBlock) {
-        const int el = idx / cmax, j = idx - el * cmax;
-        const int c = E.cls[e0 + el];
-        const unsigned short* tp = E.c_tptr + (size_t)c * (cmax + 1);
-        const unsigned short* tk = E.c_tk + (size_t)c * nzm;
-        const unsigned short* tr = E.c_trow + (size_t)c * nzm;
-        const double* ve = vs + (size_t)el * nzm;
-        double acc = 0.0;
-        int p = tp[j];
-        const int pe = tp[j + 1];
-        while (p < pe) {      // entries are sorted by row, so a node's entries are consecutive
-          const int node = tr[p] / K;
-          double bq[8];
-#pragma unroll
-          for (int a = 0; a < 8; ++a) bq[a] = 0.0;
-          for (; p < pe && tr[p] / K == node; ++p) {
-            const int a = tr[p] - node * K;
-            const double val = ve[tk[p]];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) bq[i] = (i == a) ? bq[i] + val : bq[i];
-          }
-          double yb[8];
-#pragma unroll
-          for (int a = 0; a < 8; ++a) yb[a] = bq[a];
-          apply_Y_node(P, Y + ((long long)(e0 + el) * E.block + node) * nY, yb);
-#pragma unroll
-          for (int a = 0; a < 8; ++a) acc += (a < K) ? bq[a] * yb[a] : 0.0;
+      if (live)
+        for (int rr = ln; rr < rpe; rr += TPE) {
+          double acc = 0.0;
+          for (int k = rp[rr]; k < rp[rr + 1]; ++k) acc += vs[k] * xs[entb[8 * k + 4]];
+          ds[rr] = acc;
         }
-        elbuf[(size_t)e0 * cmax + idx] = acc;
+      __syncthreads();
+      if (live)
+        for (int rr = ln; rr < rpe; rr += TPE) {
+          const int node = rr / K, a = rr - node * K;
+          const double* yq = ys + node * nY;
+          const double* dq = ds + node * K;
+          double acc = 0.0;
+          for (int i = yls.ptr[a]; i < yls.ptr[a + 1]; ++i) {
+            const unsigned pq = yls.pair[i];
+            acc += yq[pq >> 8] * dq[pq & 0xffu];
+          }
+          us[rr] = acc;
+        }
+      __syncthreads();
+      if (live)
+        for (int p = ln; p < nz; p += TPE) {
+          const unsigned w = entw[2 * p];
+          pr[p] = vs[w & 0xffffu] * us[w >> 16];
+        }
+      __syncthreads();
+      if (live)
+        for (int j = ln; j < cmax; j += TPE) {
+          double acc = 0.0;
+          for (int p = tp[j]; p < tp[j + 1]; ++p) acc += pr[p];
+          elbuf[(size_t)e * cmax + j] = acc;
+        }
+    } else if (live) {
+      // diagonal entry of column j: sum over pairs of the column's entries that sit on the same node of  b1 Y_q[a1, a2] b2
+      for (int j = ln; j < cmax; j += TPE) {
+        double acc = 0.0;
+        for (int p1 = tp[j]; p1 < tp[j + 1]; ++p1) {
+          const unsigned w1 = entw[2 * p1];
+          const int r1 = w1 >> 16, node = r1 / K, a1 = r1 - node * K;
+          const double* yq = ys + node * nY;
+          for (int p2 = tp[j]; p2 < tp[j + 1]; ++p2) {
+            const unsigned w2 = entw[2 * p2];
+            const int r2 = w2 >> 16;
+            if (r2 / K != node) continue;
+            const unsigned a2 = r2 - node * K;
+            double y = 0.0;
+            for (int i = yls.ptr[a1]; i < yls.ptr[a1 + 1]; ++i) {
+              const unsigned pq = yls.pair[i];
+              y += (pq & 0xffu) == a2 ? yq[pq >> 8] : 0.0;
+            }
+            acc += vs[w1 & 0xffffu] * y * vs[w2 & 0xffffu];
+          }
+        }
+        elbuf[(size_t)e * cmax + j] = acc;
       }
     }
   }
@@ -440,13 +494,62 @@ __global__ __launch_bounds__(kBlock) void pcg_p_kernel(int n, double* __restrict
     p[i] = (beta == 0.0) ? z[i] : z[i] + beta * p[i];
 }
 
-size_t elop_lds_bytes(const DevElOp& E) { return (size_t)E.epb * (E.cmax + E.nnz_max + E.rows_per_el) * sizeof(double); }
+YList make_ylist(const BarrierParams& P) {
+  std::vector<unsigned short> rows[8];
+  int base = 0;
+  for (int ci = 0; ci < P.ncones; ++ci) {
+    const ConeSpec& S = P.cone[ci];
+    const int nact = S.nact();
+    int slot = base;
+    for (int a = 0; a < nact; ++a)
+      for (int b = a; b < nact; ++b, ++slot) {
+        const int ra = S.col(a), rb = S.col(b);
+        rows[ra].push_back((unsigned short)(rb | slot << 8));
+        if (ra != rb) rows[rb].push_back((unsigned short)(ra | slot << 8));
+      }
+    base += S.nY();
+  }
+  YList y{};
+  int n = 0;
+  for (int a = 0; a < 8; ++a) {
+    y.ptr[a] = (unsigned char)n;
+    for (unsigned short pq : rows[a]) y.pair[n++] = pq;
+  }
+  y.ptr[8] = (unsigned char)n;
+  return y;
+}
 
 void launch_elop_phase1(hipStream_t st, const DevElOp& E, const BarrierParams& P, const double* Y, const double* v, const double* vmul,
                         const double* vscale, double* elbuf, int diag, const double* done) {
-  const int npass = (E.nel + E.epb - 1) / E.epb;
-  const int grid = std::max(1, std::min(npass, kMaxBlocks * 4));
-  hipLaunchKernelGGL(elop_apply_kernel, dim3(grid), dim3(kBlock), elop_lds_bytes(E), st, E, P, Y, v, vmul, vscale, elbuf, diag, done);
+  const int epb = kBlock / E.tpe;
+  const int npass = (E.nel + epb - 1) / epb;
+  const size_t lds = (size_t)epb * E.slot_doubles * sizeof(double);
+  const YList tab = make_ylist(P);
+  // persistent workgroups: as many as are resident on the device at once (occupancy query: LDS and registers), each walking
+  // its share of the passes with the next pass's loads in flight behind the current one's arithmetic
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+#define MGB_ELOP(T)                                                                                                            \
+  {                                                                                                                            \
+    int per_cu = 0;                                                                                                            \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, elop_apply_kernel<T>, kBlock, lds) != hipSuccess || per_cu < 1)  \
+      per_cu = 2;                                                                                                              \
+    const int grid = std::max(1, std::min(npass, ncu * per_cu));                                                               \
+    hipLaunchKernelGGL(elop_apply_kernel<T>, dim3(grid), dim3(kBlock), lds, st, E, P.K, P.nY(), tab, Y, v, vmul, vscale, elbuf,  \
+                       diag, done);                                                                                            \
+  }
+  switch (E.tpe) {
+    case 8: MGB_ELOP(8); break;
+    case 16: MGB_ELOP(16); break;
+    case 32: MGB_ELOP(32); break;
+    case 64: MGB_ELOP(64); break;
+    case 128: MGB_ELOP(128); break;
+    default: MGB_ELOP(256); break;
+  }
+#undef MGB_ELOP
 }
 
 }  // namespace

@@ -21,16 +21,17 @@ namespace mgb {
 // (B's own CSR values, contiguous per element) come from memory.
 struct DevElOp {
   int nel = 0, rows_per_el = 0, cmax = 0, K = 0, block = 0, nnz_max = 0, ncls = 0, N = 0;
-  int epb = 1;                                 // elements per workgroup pass
+  int tpe = 256;                               // threads per element (power of two, 8 .. 256): 256 / tpe elements per workgroup pass
+  int slot_doubles = 0;                        // LDS per element, in doubles: xs, vs, ds, us, ys and the element's copy of its class table
   const int* ecols = nullptr;                  // nel x cmax (padded with the element's first column; padded slots are never gathered)
   const int* cls = nullptr;                    // nel
   const int* rowptr = nullptr;                 // B's rowptr (element e's nonzeros start at rowptr[e * rows_per_el])
   const double* vals = nullptr;                // B's values
   const unsigned short* c_rowptr = nullptr;    // ncls x (rows_per_el + 1), relative to the element's first nonzero
-  const unsigned char* c_lcol = nullptr;       // ncls x nnz_max: local column of every nonzero (row-major order)
   const unsigned short* c_tptr = nullptr;      // ncls x (cmax + 1): column-wise traversal
-  const unsigned short* c_tk = nullptr;        // ncls x nnz_max: local nonzero index, sorted by (column, row)
-  const unsigned short* c_trow = nullptr;      // ncls x nnz_max: its local row
+  // ncls x nnz_max, one 64-bit entry per nonzero: bits 0-15 local nonzero index and 16-31 local row of the p-th entry in
+  // column-wise order (sorted by column, then row); bits 32-39 local column of the k-th entry in row-wise order
+  const unsigned long long* c_ent = nullptr;
   // gather of the element results: out[i] = sum_{p in dptr[i] .. dptr[i + 1]} elbuf[didx[p]], fixed order -> reproducible
   const int* dptr = nullptr;
   const int* didx = nullptr;
