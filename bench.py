@@ -150,6 +150,12 @@ def parse_args(argv=None):
     ap.add_argument("--probe-L", type=int, default=9,
                     help="after the timed region, HIP-event time the barrier / SpMV kernels on this larger mesh with rotating "
                          "buffers (0 = skip): the size at which they leave the launch-latency regime")
+    ap.add_argument("--solver", choices=("gpu", "pcg"), default="gpu",
+                    help="Newton linear solver: device multifrontal Cholesky (default) or V-cycle-preconditioned CG with the "
+                         "matrix-free Hessian (single GPU; DESIGN.md section 4c says where each wins)")
+    ap.add_argument("--comm", choices=("rccl", "callback"), default="rccl",
+                    help="sharded runs: collectives through the library-owned RCCL communicator on the context stream (default) or "
+                         "through the torch.distributed callback (what --rehearse-one-gpu needs: RCCL refuses two ranks on one GPU)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N>1 on a single-GPU box: every rank uses cuda:0 and torch.distributed runs on gloo (RCCL refuses "
                          "two ranks on one device); exercises the multi-rank control flow, not a measurement")
@@ -185,7 +191,12 @@ def main():
     backend = M.backend_hip(dev)
     sharded = bool(world > 1 and not args.replicas)
     if sharded:      # one solve over all ranks: row blocks + RCCL allreduce
-        backend.set_comm(rank, world, M.torch_allreduce(dist, dev))
+        if args.comm == "rccl" and not args.rehearse_one_gpu:
+            M.rccl_comm_from_torch(backend, dist)      # the library owns the communicator; torch only carried the 128-byte id
+        else:
+            backend.set_comm(rank, world, M.torch_allreduce(dist, dev))
+    if sharded and args.solver != "gpu":
+        raise SystemExit("bench.py: --solver pcg runs on one GPU")
 
     # preload code objects and the HIP context with a tiny solve (not a warmup step of the workload): `setup_s` below is the
     # hierarchy build of a warm process, as the reference's benchmark times its larger meshes after the smaller ones have
@@ -206,6 +217,7 @@ def main():
     z0 = M._rows(M.DEFAULT_G[2], x).reshape(-1, order="F")
     c = M._rows(M.DEFAULT_F[2], x)
     A.set_c(c)
+    A.set_solver(args.solver)
     A.prepare()                  # operators, Hessian plan, factorisation structures: setup, not solve
     backend.synchronize()
     t_setup = time.time() - t_setup
@@ -214,7 +226,7 @@ def main():
 
     def one_solve():
         A.set_z(z0)
-        return A.solve(verbose=args.verbose)
+        return A.solve(verbose=args.verbose, solver=args.solver)
 
     for _ in range(args.warmup):
         one_solve()
@@ -255,17 +267,19 @@ def main():
         achieved = kd["bytes"] / max(kd["ms"], 1e-12) / 1e6      # GB/s = bytes / ms / 1e6
         # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # runs of this same command, gfx950 FETCH_SIZE x2 correction applied); null for other workloads
-        traffic = None
-        for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        # (not measured in this run: `traffic_source` names the committed file; null when no committed pass covers the kernel)
+        traffic, traffic_source = None, None
+        for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pmc.get("workload") == "fem2d L=%d p=%g" % (args.L, args.p) and dom in pmc["kernels"]:
                     traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+                    traffic_source = "profiles/" + name + " (committed rocprofv3 --pmc passes of this command, not this run)"
                     break
             except Exception:
                 continue
         roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source,
                         avg_launch_us=1e3 * kd["ms"] / max(kd["launches"], 1), launches_timed=kd["launches"],
                         algorithmic_bytes_per_launch=kd["bytes"] / max(kd["launches"], 1),
                         note="latency-bound at this size: every working set is L2/Infinity-Cache resident and the "
@@ -289,7 +303,8 @@ def main():
             "total_solve_s": elapsed / args.steps, "setup_s": t_setup,
             "total_solve_s_incl_setup": t_setup + elapsed / args.steps,
             "newton_steps_per_solve": newton_steps / args.steps,
-            "linear_solver": "gpu multifrontal Cholesky (csrc/gpuchol.hip)",
+            "linear_solver": "gpu multifrontal Cholesky (csrc/gpuchol.hip)" if args.solver == "gpu" else
+                             "V-cycle-preconditioned CG, matrix-free Hessian (csrc/mg.hip), direct fallback",
             "linear_solve_s_per_solve": sum(s["time_factor"] for s in sols) / args.steps,
             "barrier_spmv_kernel_s_per_solve": sum(est[k] for k in kern if not k.startswith("chol_")) / 1e3 / args.steps,
             "t_final": float(last["ts"][-1]), "c_dot_Dz_final": float(last["c_dot_Dz"][-1]),
@@ -302,16 +317,24 @@ def main():
             zo = gz["z"].reshape(-1, order="F")
             relz = float(np.linalg.norm(z_final - zo) / np.linalg.norm(zo))
             relc = float(abs(out["c_dot_Dz_final"] - gz["c_dot_Dz"][-1]) / abs(gz["c_dot_Dz"][-1]))
-            out["parity"] = {"z_rel_l2_vs_oracle": relz, "c_dot_Dz_rel_vs_oracle": relc, "tolerance": 1e-10,
+            PARITY_TOL = 1e-10      # the gate below uses the tolerance it reports
+            out["parity"] = {"z_rel_l2_vs_oracle": relz, "c_dot_Dz_rel_vs_oracle": relc, "tolerance": PARITY_TOL,
                              "oracle_newton_steps": int(gz["its"].sum()), "fixture": os.path.basename(gold)}
             if "z_centre" in gz.files:       # the oracle's end point polished to the exact centre (tests/golden/polish_centre.py)
                 zc = gz["z_centre"].reshape(-1, order="F")
                 out["parity"]["z_rel_l2_vs_oracle_centre"] = float(np.linalg.norm(z_final - zc) / np.linalg.norm(zc))
-            if not (relz < 1e-8 and relc < 1e-8):
+            if not (relz < PARITY_TOL and relc < 1e-9):
                 print(json.dumps(out))
                 raise SystemExit("bench.py: the timed solve does not reproduce the oracle's z (rel l2 %.3e)" % relz)
+        if args.solver == "pcg":
+            out["pcg"] = {k: sum(s["pcg"][k] for s in sols) for k in ("solves", "iterations", "fallbacks", "seconds")}
+            out["pcg"]["gave_up_at_newton_system"] = last["pcg"]["gave_up_at"]
         if sharded:
             st = {k: comm1[k] - comm0[k] for k in comm1}      # the timed solves only
+            out["communicator"] = ("library-owned RCCL (ncclAllReduce on the context stream)" if backend._allreduce_cb is None
+                                   else "torch.distributed callback (host-synchronised)")
+            out["multi_gpu_status"] = ("rehearsal on one GPU over gloo: control flow and parity only" if args.rehearse_one_gpu else
+                                       "measured on %d GPUs" % world)
             info = A.chol_info()
             out["allreduce"] = dict(st, per_newton_step={"collectives": st["calls"] / max(newton_steps, 1),
                                                          "bytes": st["bytes"] / max(newton_steps, 1)},

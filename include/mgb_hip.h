@@ -205,6 +205,12 @@ int mgb_amg_set_schedule(mgb_amg a, int all_levels);
  * reference ([UPSTREAM-UNVERIFIED]; SOL_main.ts is an observable, docs/src/api.md:97-101); both visit the same ts when kappa is
  * never reduced. */
 int mgb_amg_set_stop_rule(mgb_amg a, int upstream);
+/* Newton's stopping rule on the finest level at the intermediate t: 1 (default) = stagnation of the objective at every t; 0 = stop
+ * once the Newton decrement <g, n> is below 0.01 min w -- the path is followed, not resolved -- and keep the stagnation rule for the
+ * last t, whose centre is the answer.  Same end point; 15-17 % fewer Newton steps at p = 1.5 / in 3-D, but MORE at p = 1 (fem2d
+ * L=7: 466 -> 580), hence the default.  A phase with mgb_amg_set_early_stop resolves every centre.  [UPSTREAM-UNVERIFIED] like
+ * every stopping constant (oracle CENTERING). */
+int mgb_amg_set_centering(mgb_amg a, int exact);
 /* amgb main phase: t-continuation x level loop x Newton; z updated in place */
 int mgb_amg_solve(mgb_amg a, double tol, double t0, double kappa, int maxit, int max_newton, int verbose);
 /* feasibility phases (SOL_feasibility, src:428-455): make mgb_amg_solve return after the first centering at which row `col`

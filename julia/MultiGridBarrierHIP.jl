@@ -4,14 +4,15 @@
 # conversions native_to_mpi / mpi_to_native (src:259-517) and the fem{1,2,3}d_mpi[_solve] wrappers (src:559-745), with
 # device arrays that are thin handles into the C ABI.
 #
-# STATUS: written blind.  The build image has no Julia toolchain (SURVEY.md section 8c), so this file has never been
-# executed; every ccall below is exercised through the identical ctypes binding (multigridbarriermpi.jl_amd/_lib.py) by
-# the Python test-suite.  Keep the two bindings in step.
+# STATUS: written blind.  The build image has no Julia toolchain (SURVEY.md section 8c), so this file has never been LOADED by
+# Julia -- lowering and dispatch are unchecked; what is checked (tests/test_host_logic.py) is that every ccall names a declared
+# entry point with the declared number and kinds of arguments.  Every entry point is exercised through the identical ctypes
+# binding (multigridbarriermpi.jl_amd/_lib.py) by the Python test-suite.  Keep the two bindings in step.
 module MultiGridBarrierHIP
 
 using LinearAlgebra, SparseArrays
 using MultiGridBarrier
-using MultiGridBarrier: Geometry, AMGBSOL, ParabolicSOL, fem1d, fem2d, fem3d
+using MultiGridBarrier: Geometry, AMGBSOL, ParabolicSOL, fem1d, fem2d, fem3d, amgb, parabolic_solve
 import MultiGridBarrier: amgb_zeros, amgb_all_isfinite, amgb_diag, amgb_blockdiag, map_rows, map_rows_gpu,
                          vertex_indices, _raw_array, _to_cpu_array, _rows_to_svectors
 
@@ -180,8 +181,8 @@ vertex_indices(A::Union{HIPVector,HIPMatrix}) = 1:size(A, 1)                    
 
 # map_rows (src:161-170).  An arbitrary Julia closure cannot cross a C ABI: it is evaluated on the host on a device->host
 # copy and the result goes back up -- the trade the reference makes with _to_cpu_array (src:183-188).  The barrier family of
-# the Newton hot path never comes through here: `amgb` below hands the whole solve to the library, whose fused kernels
-# evaluate F / F1 / F2 of `convex_Euclidian_power` (and of intersections of two such cones).
+# the Newton hot path never comes through here: the `MultiGridBarrier.amgb(::HIPGeometry)` method at the end of this file hands
+# the whole solve to the library, whose fused kernels evaluate F / F1 / F2 of `convex_Euclidian_power` (and intersections).
 const AnyHIP = Union{HIPVector,HIPMatrix}
 function map_rows(f, A::AnyHIP, args...)
     host = map(a -> a isa HIPMatrix ? Matrix(a) : a isa HIPVector ? Vector(a) : a, (A, args...))
@@ -212,9 +213,11 @@ MultiGridBarrier.solve(A::HIPSparseMatrix, b::HIPVector) = HIPVector(SparseMatri
 "native_to_mpi counterpart (src:259-338): same key order (sorted), Ti = Int32, arrays become device handles."
 function native_to_hip(g::Geometry; backend::HIPBackend = backend_hip())
     up(S) = HIPSparseMatrix(SparseMatrixCSC{Float64,Int}(S), backend)
-    ops = Dict(k => up(g.operators[k]) for k in sort(collect(keys(g.operators))))
-    subs = Dict(k => [up(S) for S in g.subspaces[k]] for k in sort(collect(keys(g.subspaces))))
-    Geometry(g.discretization, HIPMatrix(g.x, backend), HIPVector(g.w, backend), subs, ops, [up(S) for S in g.refine], [up(S) for S in g.coarsen])
+    ops = Dict{Symbol,HIPSparseMatrix}(k => up(g.operators[k]) for k in sort(collect(keys(g.operators))))
+    subs = Dict{Symbol,Vector{HIPSparseMatrix}}(k => HIPSparseMatrix[up(S) for S in g.subspaces[k]] for k in sort(collect(keys(g.subspaces))))
+    Geometry{Float64,HIPMatrix,HIPVector,HIPSparseMatrix,typeof(g.discretization)}(                  # explicit parameters, as src:329
+        g.discretization, HIPMatrix(g.x, backend), HIPVector(g.w, backend), subs, ops,
+        HIPSparseMatrix[up(S) for S in g.refine], HIPSparseMatrix[up(S) for S in g.coarsen])
 end
 "mpi_to_native counterpart (src:355-517): gathers geometry, AMGBSOL and ParabolicSOL back to native arrays."
 hip_to_native(x::HIPVector) = Vector(x)
@@ -229,59 +232,141 @@ hip_to_native(s::AMGBSOL) = AMGBSOL(hip_to_native(s.z), hip_to_native(s.SOL_feas
 hip_to_native(s::ParabolicSOL) = ParabolicSOL(hip_to_native(s.geometry), s.ts, hip_to_native.(s.u))
 
 # ---------------------------------------------------------------------------------------------- whole solves on the GPU
-# fem{1,2,3}d_hip_solve keep the kwargs of fem{1,2,3}d_mpi_solve (src:594-600, 661-667, 735-745).  The geometry is built by
-# the library's own builder (mgb_fem*_native, the same refinement / node order as MultiGridBarrier.fem*d pinned by
-# tests/test_host_logic.py), the AMG hierarchy and the barrier problem live in HBM, and mgb_amg_solve runs the main phase.
-const _D = Dict(1 => ["u", "id", "u", "dx", "s", "id"], 2 => ["u", "id", "u", "dx", "u", "dy", "s", "id"],
-                3 => ["u", "id", "u", "dx", "u", "dy", "u", "dz", "s", "id"])                     # src:736
-function _solve(geo::Handle, dim::Int, x::Matrix{Float64}; p = 1.0, tol = sqrt(eps()), t = 0.1, kappa = 10.0, maxit = 10000,
-                f = x -> [0.5; zeros(dim); 1.0], g = x -> dim == 1 ? [x[1], 2.0] : [sum(abs2, x), 100.0], verbose = false,
-                backend::HIPBackend = backend_hip(), kwargs...)
-    sv, D, n, K = ["u", "dirichlet", "s", "full"], _D[dim], size(x, 1), dim + 2
+# `amgb` / `parabolic_solve` on a Geometry whose arrays are HIP types hand the WHOLE solve to the library (the per-row hooks above
+# are for callers that use the array types directly): the caller's geometry is uploaded matrix by matrix (the native_to_mpi
+# input side, src:259-302), the AMG hierarchy and the barrier problem live in HBM, mgb_amg_solve runs the main phase.
+const HIPGeometry{T,D} = Geometry{T,HIPMatrix,HIPVector,HIPSparseMatrix,D}
+_csr0(S) = (T = SparseMatrixCSC{Float64,Int32}(sparse(transpose(SparseMatrixCSC(S)))); (T.colptr .- Int32(1), T.rowval .- Int32(1), T.nzval))
+"rows per element = size of the diagonal blocks of an element-local operator (1 if it has none)"
+function _block_size(S::SparseMatrixCSC)
+    n, hi, start, sizes = size(S, 1), 0, 1, Int[]
+    T = sparse(transpose(S))                                         # column i of T = row i of S
+    for i in 1:n
+        hi = max(hi, i, maximum(rowvals(T)[nzrange(T, i)]; init = i))
+        hi == i && (push!(sizes, i - start + 1); start = i + 1)
+    end
+    all(==(sizes[1]), sizes) ? sizes[1] : 1
+end
+function _geo_handle(g::Geometry)
+    x, w = Matrix{Float64}(hip_to_native(g.x)), Vector{Float64}(hip_to_native(g.w))
+    n, dim, L = size(x, 1), size(x, 2), length(g.refine)
+    dx = SparseMatrixCSC(g.operators[:dx])
+    h = Ref{Handle}(C_NULL)
+    @mgb mgb_geo_create (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Handle}) n dim L _block_size(dx) vec(permutedims(x)) w h
+    put(name, S) = begin
+        rp, ci, va = _csr0(S)
+        @mgb mgb_geo_set_matrix (Handle, Cstring, Cint, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Cdouble}) h[] name size(S, 1) size(S, 2) rp ci va
+    end
+    foreach(k -> put("op:$k", g.operators[k]), sort(collect(keys(g.operators))))                  # sorted keys, src:271-302
+    for k in sort(collect(keys(g.subspaces))), (l, S) in enumerate(g.subspaces[k]); put("sub:$k:$(l - 1)", S); end
+    for (l, S) in enumerate(g.refine); put("refine:$(l - 1)", S); end
+    for (l, S) in enumerate(g.coarsen); put("coarsen:$(l - 1)", S); end
+    h[]
+end
+_pairs(M) = String[string(M[i, j]) for i in 1:size(M, 1) for j in 1:2]                             # [:u :dirichlet; :s :full] -> flat strings
+_rows(f, x) = permutedims(reduce(hcat, [Float64.(collect(f(x[i, :]))) for i in 1:size(x, 1)]))
+"barrier terms in the encoding of mgb_amg_create_terms: cones = [(idx::Vector{Int} (1-based rows of D: q..., s), p)]"
+function _amg(geo::Handle, b::HIPBackend, sv, D, cones)
+    K, nt = size(D, 1), length(cones)
+    kind, nq, iq, is, is2 = zeros(Cint, nt), Cint[length(c[1]) - 1 for c in cones], zeros(Cint, 3nt), Cint[c[1][end] - 1 for c in cones], fill(Cint(-1), nt)
+    for (c, (idx, _)) in enumerate(cones), i in 1:length(idx)-1; iq[3(c-1)+i] = idx[i] - 1; end
     a = Ref{Handle}(C_NULL)
-    @mgb mgb_amg_create (Handle, Handle, Cint, Ptr{Cstring}, Cint, Ptr{Cstring}, Cint, Ptr{Cint}, Cint, Cdouble, Ref{Handle}) backend.h geo 2 sv K D dim Cint.(1:dim) (dim + 1) p a
+    @mgb mgb_amg_create_terms (Handle, Handle, Cint, Ptr{Cstring}, Cint, Ptr{Cstring}, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Handle}) b.h geo size(sv, 1) _pairs(sv) K _pairs(D) nt kind nq iq is is2 Cdouble[c[2] for c in cones] C_NULL C_NULL a
+    a[]
+end
+function _run(a::Handle, n::Int, S::Int, c::Matrix{Float64}, z::Matrix{Float64}; tol, t, kappa, maxit, verbose, solver = 0)
+    @mgb mgb_amg_set_c (Handle, Ptr{Cdouble}) a vec(permutedims(c))
+    @mgb mgb_amg_set_z (Handle, Ptr{Cdouble}) a vec(z)
+    @mgb mgb_amg_set_solver (Handle, Cint) a solver
+    @mgb mgb_amg_prepare (Handle, Cint) a (-1)
+    @mgb mgb_amg_solve (Handle, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint) a tol t kappa maxit 0 (verbose ? 1 : 0)
+    zo = Vector{Float64}(undef, n * S)
+    @mgb mgb_amg_get_z (Handle, Ptr{Cdouble}) a zo
+    nt, te, L = Ref{Cint}(0), Ref{Cdouble}(0), Ref{Cint}(0)
+    @mgb mgb_amg_sol_info (Handle, Ref{Cint}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Clonglong}) a nt te C_NULL C_NULL
+    @mgb mgb_amg_dims (Handle, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ref{Cint}, Ptr{Cint}) a C_NULL C_NULL C_NULL L C_NULL
+    its, ts, cd = Matrix{Clonglong}(undef, L[], nt[]), Vector{Float64}(undef, nt[]), Vector{Float64}(undef, nt[])
+    @mgb mgb_amg_sol_get (Handle, Ptr{Clonglong}, Ptr{Cdouble}, Ptr{Cdouble}) a its ts cd
+    reshape(zo, n, S), (t_elapsed = te[], ts = ts, its = Int.(its), c_dot_Dz = cd)                   # SOL_main fields, api.md:97-101
+end
+_default_D(dim) = dim == 1 ? [:u :id; :u :dx; :s :id] : dim == 2 ? [:u :id; :u :dx; :u :dy; :s :id] : [:u :id; :u :dx; :u :dy; :u :dz; :s :id]   # src:736
+"MultiGridBarrier.amgb on a HIP geometry (called at src:599,666,744): returns AMGBSOL in the reference's field order (src:467-473)."
+function MultiGridBarrier.amgb(geometry::HIPGeometry{T,Dsc}; p = one(T), state_variables = [:u :dirichlet; :s :full],
+                               D = _default_D(size(geometry.x, 2)), f = x -> [0.5; zeros(length(x)); 1.0],
+                               g = x -> length(x) == 1 ? [x[1], 2.0] : [sum(abs2, x), 100.0],                          # src:737-738
+                               tol = sqrt(eps(Float64)), t = 0.1, kappa = 10.0, maxit = 10000, verbose = false, logfile = nothing,
+                               solver = 0, kwargs...) where {T,Dsc}
+    gfun, g = g, geometry
+    dim, b, x = size(g.x, 2), g.x.v.backend, Matrix(g.x)
+    n, K, S = size(x, 1), size(D, 1), size(state_variables, 1)
+    idx = collect(K-dim:K)                                                                           # convex_Euclidian_power(idx = 2:dim+2)
+    geo = _geo_handle(g)
+    a = _amg(geo, b, state_variables, D, [(idx, Float64(p))])
     try
-        c = permutedims(reduce(hcat, [Float64.(f(x[i, :])) for i in 1:n]))                       # n x K, row-major for the ABI below
-        z0 = permutedims(reduce(hcat, [Float64.(g(x[i, :])) for i in 1:n]))                      # n x S
-        @mgb mgb_amg_set_c (Handle, Ptr{Cdouble}) a[] vec(permutedims(c))
-        @mgb mgb_amg_set_z (Handle, Ptr{Cdouble}) a[] vec(z0)
-        @mgb mgb_amg_prepare (Handle, Cint) a[] (-1)
-        @mgb mgb_amg_solve (Handle, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint) a[] tol t kappa maxit 0 (verbose ? 1 : 0)
-        z = Vector{Float64}(undef, 2n)
-        @mgb mgb_amg_get_z (Handle, Ptr{Cdouble}) a[] z
-        nt, te = Ref{Cint}(0), Ref{Cdouble}(0)
-        @mgb mgb_amg_sol_info (Handle, Ref{Cint}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Clonglong}) a[] nt te C_NULL C_NULL
-        L = Ref{Cint}(0)
-        @mgb mgb_amg_dims (Handle, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ref{Cint}, Ptr{Cint}) a[] C_NULL C_NULL C_NULL L C_NULL
-        its, ts, cd = Matrix{Clonglong}(undef, L[], nt[]), Vector{Float64}(undef, nt[]), Vector{Float64}(undef, nt[])
-        @mgb mgb_amg_sol_get (Handle, Ptr{Clonglong}, Ptr{Cdouble}, Ptr{Cdouble}) a[] its ts cd
-        (z = reshape(z, n, 2), SOL_feasibility = nothing, SOL_main = (t_elapsed = te[], ts = ts, its = Int.(its), c_dot_Dz = cd))   # api.md:97-101
+        c, z0 = _rows(f, x), _rows(gfun, x)
+        # feasibility phase (SOL_feasibility, src:428-455), closed form for the power cone whose slack is `id` of a :full variable:
+        # shift that variable by sigma = 1 + max(|q|^p - s) (Dz at s = 0 from the device)
+        @mgb mgb_amg_set_c (Handle, Ptr{Cdouble}) a vec(permutedims(c))
+        @mgb mgb_amg_set_z (Handle, Ptr{Cdouble}) a vec(z0)
+        N = Ref{Cint}(0)
+        @mgb mgb_amg_level_size (Handle, Cint, Ref{Cint}, Ptr{Cint}) a (length(g.refine) - 1) N C_NULL
+        Dz = Matrix{Float64}(undef, K, n)                                                            # row-major n x K behind the ABI
+        @mgb mgb_amg_apply_D (Handle, Cint, Ptr{Cdouble}, Ptr{Cdouble}) a (length(g.refine) - 1) zeros(N[]) Dz
+        viol = [sqrt(sum(abs2, Dz[idx[1:end-1], i]))^p - Dz[idx[end], i] for i in 1:n]
+        feas = nothing
+        if maximum(viol) >= 0
+            sigma = 1 + maximum(viol)
+            svar = findfirst(==(D[idx[end], 1]), state_variables[:, 1])
+            (D[idx[end], 2] == :id && state_variables[svar, 2] == :full) || error("amgb: feasibility phase needs the cone's slack to be `id` of a :full variable")
+            z0[:, svar] .+= sigma
+            feas = (shift = sigma, ts = Float64[], its = zeros(Int, length(g.refine), 0), c_dot_Dz = Float64[], t_elapsed = 0.0)
+        end
+        z, main = _run(a, n, S, c, z0; tol = tol, t = t, kappa = kappa, maxit = maxit, verbose = verbose, solver = solver)
+        zh = HIPMatrix(z, b)
+        AMGBSOL{T,typeof(zh),typeof(g.w),HIPSparseMatrix,Dsc}(zh, feas, main, String[], g)           # src:467-473
     finally
-        ccall((:mgb_amg_destroy, LIB), Cint, (Handle,), a[])
+        ccall((:mgb_amg_destroy, LIB), Cint, (Handle,), a)
+        ccall((:mgb_geo_destroy, LIB), Cint, (Handle,), geo)
     end
 end
-function _native(builder::Symbol, dim::Int, args...)
-    g = Ref{Handle}(C_NULL)
-    check(ccall((builder, LIB), Cint, (typeof.(args)..., Ref{Handle}), args..., g))
-    n, d = Ref{Cint}(0), Ref{Cint}(0)
-    @mgb mgb_geo_dims (Handle, Ref{Cint}, Ref{Cint}, Ptr{Cint}, Ptr{Cint}) g[] n d C_NULL C_NULL
-    xt = Matrix{Float64}(undef, dim, n[])
-    @mgb mgb_geo_get_xw (Handle, Ptr{Cdouble}, Ptr{Cdouble}) g[] xt C_NULL
-    g[], permutedims(xt)
+"MultiGridBarrier.parabolic_solve on a HIP geometry (src:22,54; ParabolicSOL src:512-516): implicit Euler, per step the two-cone problem s1 >= u^2, s2 >= |grad u|^p."
+function MultiGridBarrier.parabolic_solve(geometry::HIPGeometry{T,Dsc}; h = 0.2, t0 = 0.0, t1 = 1.0, p = one(T), f1 = x -> 0.5,
+                                          g = x -> length(x) == 1 ? [x[1], 2.0] : [sum(abs2, x), 100.0], tol = sqrt(eps(Float64)),
+                                          verbose = false, kwargs...) where {T,Dsc}
+    gfun, g = g, geometry
+    dim, b, x = size(g.x, 2), g.x.v.backend, Matrix(g.x)
+    n, K = size(x, 1), dim + 3
+    sv = [:u :dirichlet; :s1 :full; :s2 :full]
+    D = vcat([:u :id], reduce(vcat, [[:u o] for o in (:dx, :dy, :dz)[1:dim]]), [:s1 :id; :s2 :id])
+    geo = _geo_handle(g)
+    a = _amg(geo, b, sv, D, [([1, K - 1], 2.0), (vcat(collect(2:dim+1), K), Float64(p))])
+    try
+        u0 = [Float64(gfun(x[i, :])[1]) for i in 1:n]
+        grad2 = sum(abs2.(SparseMatrixCSC(g.operators[o]) * u0) for o in (:dx, :dy, :dz)[1:dim])
+        z = hcat(u0, fill(1 + maximum(abs2, u0), n), fill(1 + maximum(grad2 .^ (p / 2)), n))
+        fg = [Float64(f1(x[i, :])) for i in 1:n]
+        ts = collect(t0:h:t1)
+        u = [HIPMatrix(z, b)]
+        for _ in 2:length(ts)
+            c = zeros(n, K)
+            c[:, 1] = fg .- z[:, 1] ./ h
+            c[:, K-1] .= 1 / (2h)
+            c[:, K] .= 1 / p
+            z, _ = _run(a, n, 3, c, z; tol = tol, t = 0.1, kappa = 10.0, maxit = 10000, verbose = verbose)
+            push!(u, HIPMatrix(z, b))
+        end
+        ParabolicSOL(g, ts, u)                                                                       # src:512-516
+    finally
+        ccall((:mgb_amg_destroy, LIB), Cint, (Handle,), a)
+        ccall((:mgb_geo_destroy, LIB), Cint, (Handle,), geo)
+    end
 end
-function fem1d_hip_solve(::Type{Float64} = Float64; L = 4, kwargs...)
-    geo, x = _native(:mgb_fem1d_native, 1, Cint(L))
-    try _solve(geo, 1, x; kwargs...) finally ccall((:mgb_geo_destroy, LIB), Cint, (Handle,), geo) end
-end
-function fem2d_hip_solve(::Type{Float64} = Float64; L = 2, kwargs...)
-    geo, x = _native(:mgb_fem2d_native, 2, Cint(L), Ptr{Cdouble}(C_NULL), Cint(0))
-    try _solve(geo, 2, x; kwargs...) finally ccall((:mgb_geo_destroy, LIB), Cint, (Handle,), geo) end
-end
-function fem3d_hip_solve(::Type{Float64} = Float64; L = 2, k = 3, kwargs...)
-    geo, x = _native(:mgb_fem3d_native, 3, Cint(L), Cint(k))
-    try _solve(geo, 3, x; kwargs...) finally ccall((:mgb_geo_destroy, LIB), Cint, (Handle,), geo) end
+# the reference's entry-point names (src:559,594,626,661,696,735) with backend = backend_hip(): kwargs go to both callees
+for (mk, sol, fem) in ((:fem1d_mpi, :fem1d_mpi_solve, :fem1d), (:fem2d_mpi, :fem2d_mpi_solve, :fem2d), (:fem3d_mpi, :fem3d_mpi_solve, :fem3d))
+    @eval $mk(::Type{T} = Float64; backend::HIPBackend = backend_hip(), kwargs...) where {T} = native_to_hip($fem(T; kwargs...); backend = backend)
+    @eval $sol(::Type{T} = Float64; kwargs...) where {T} = MultiGridBarrier.amgb($mk(T; kwargs...); kwargs...)
 end
 
-export HIPBackend, backend_hip, HIPVector, HIPMatrix, HIPSparseMatrix, native_to_hip, hip_to_native,
-       fem1d_hip_solve, fem2d_hip_solve, fem3d_hip_solve, MGBError
+export HIPBackend, backend_hip, HIPVector, HIPMatrix, HIPSparseMatrix, HIPGeometry, native_to_hip, hip_to_native,
+       fem1d_mpi, fem2d_mpi, fem3d_mpi, fem1d_mpi_solve, fem2d_mpi_solve, fem3d_mpi_solve, MGBError
 end # module

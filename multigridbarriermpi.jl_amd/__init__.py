@@ -1045,12 +1045,15 @@ class AMG:
         return c0.value
 
     def solve(self, tol=None, t=0.1, kappa=10.0, maxit=10000, max_newton=0, verbose=0, schedule="fine",
-              solver="gpu", stop_rule="fixed"):
+              solver="gpu", stop_rule="fixed", centering="exact"):
         if schedule not in ("fine", "all"):
             raise ValueError("schedule must be 'fine' or 'all'")
         if stop_rule not in ("fixed", "upstream"):
             raise ValueError("stop_rule must be 'fixed' or 'upstream'")
+        if centering not in ("decrement", "exact"):
+            raise ValueError("centering must be 'decrement' or 'exact'")
         call("mgb_amg_set_stop_rule", self.handle, 1 if stop_rule == "upstream" else 0)
+        call("mgb_amg_set_centering", self.handle, 1 if centering == "exact" else 0)
         call("mgb_amg_set_schedule", self.handle, 1 if schedule == "all" else 0)
         self.set_solver(solver)
         call("mgb_amg_solve", self.handle, float(tol or 0.0), float(t), float(kappa), int(maxit), int(max_newton),
@@ -1154,7 +1157,7 @@ def _phase1_slack(geometry, M: "AMG", p, z0, c, tol, schedule, solver):
 
 def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=None, g=None, tol=None, t=0.1,
          maxit=10000, kappa=10.0, verbose=False, logfile=None, schedule="fine", solver="gpu", cones=None, stop_rule="fixed",
-         **rest) -> AMGBSOL:
+         centering="exact", **rest) -> AMGBSOL:
     """MultiGridBarrier.amgb on an MPI geometry (called at src:599,666).  kwargs as documented in
     docs/src/guide.md:148-152; unknown kwargs (e.g. `L`, forwarded by fem*d_mpi_solve, src:663-666)
     are ignored like Julia's `kwargs...` fan-out.  `cones` (upstream kwarg `Q`: the convex set) selects the barrier terms,
@@ -1205,7 +1208,7 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
         M.set_pcg(**rest["pcg"])      # parameters of solver="pcg", see AMG.set_pcg
     M.prepare()       # factorisation structures are setup, not solve time (SOL_main.t_elapsed mirrors the reference's)
     SOL = M.solve(tol=tol, t=t, kappa=kappa, maxit=maxit, verbose=2 if verbose and verbose > 1 else int(bool(verbose)),
-                  schedule=schedule, solver=solver, stop_rule=stop_rule)
+                  schedule=schedule, solver=solver, stop_rule=stop_rule, centering=centering)
     z = M.get_z().reshape(z0.shape, order="F")
     return AMGBSOL(HPCMatrix(z, geometry.x.backend), SOL_feasibility, SOL, [], geometry)
 

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "mgb_amg_set_solver": [H, C.c_int],
     "mgb_amg_set_schedule": [H, C.c_int],
     "mgb_amg_set_stop_rule": [H, C.c_int],
+    "mgb_amg_set_centering": [H, C.c_int],
     "mgb_amg_set_pcg": [H, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int],
     "mgb_amg_sol_pcg": [H, c_ll_p, c_dbl_p],
     "mgb_hessian_apply": [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, C.c_int],

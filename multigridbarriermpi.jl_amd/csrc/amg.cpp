@@ -990,7 +990,7 @@ bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, do
 // kFracToBoundary (amg.hpp) = oracle FRAC_TO_BOUNDARY; the loop below mirrors oracle newton() +
 // linesearch_backtracking() (REFINE = True) statement by statement.
 
-Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int maxit, SolveStats& st, int verbose) {
+Amg::NewtonResult Amg::newton(int l, double t, bool finest, bool final, double lam_tol, int maxit, SolveStats& st, int verbose) {
   Level& lv = level(l);
   const int N = lv.plan.N;
   NewtonResult res;
@@ -1122,7 +1122,10 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
         hip_check(hipMemcpy(lv.h_g.p, lv.g.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost), "D2H g");
     }
     const bool exact = ynext >= ymin && gnext >= theta * gmin;
-    if ((!finest && inc < lam_tol) || exact) res.converged = true;
+    // the decrement rule everywhere but on the finest level at the last t (oracle amgb_step: stopping_inexact / stopping_exact)
+    // finest level: w F is self-concordant only after division by w, so the threshold is a fraction of min w (oracle DECREMENT_FRAC)
+    const double dec_tol = finest ? kDecrementFrac * w_min_ : lam_tol;
+    if ((!(finest && final) && inc < dec_tol) || exact) res.converged = true;
     y = ynext;
     gnorm = gnext;
     ymin = std::min(ymin, y);
@@ -1144,13 +1147,13 @@ Amg::NewtonResult Amg::newton(int l, double t, bool finest, double lam_tol, int 
   return res;
 }
 
-bool Amg::amgb_step(double t, double lam_tol, int max_newton, std::vector<long long>& its, SolveStats& st, int verbose) {
+bool Amg::amgb_step(double t, bool final, double lam_tol, int max_newton, std::vector<long long>& its, SolveStats& st, int verbose) {
   const int L = (int)levels_.size();
   bool converged = true;
   // level schedule: finest level only (default) or the literal coarse -> fine loop (oracle LEVEL_SCHEDULE)
   for (int J = (schedule_all_ ? 0 : L - 1); J < L; ++J) {
     Level& lv = level(J);
-    NewtonResult r = newton(J, t, J == L - 1, lam_tol, max_newton, st, verbose);
+    NewtonResult r = newton(J, t, J == L - 1, final, lam_tol, max_newton, st, verbose);
     its[J] += r.k;
     if (lv.plan.N > 0) {
       launch_spmv(ctx_.stream, lv.R.view, lv.s.p, z_.p, z_.p);
@@ -1221,25 +1224,27 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   seq_expected_ = *h_seq_.p;
   std::vector<long long> its(L, 0);
   refresh_dz0();
+  // the continuation ends at a FIXED t: the first value of the nominal sequence t0 kappa0^k beyond 1 / tol (oracle amgb_core:
+  // otherwise the last t, and with it z to ~1e-6, depends on the rounding-sensitive history of kappa reductions)
+  double t_stop = t;
+  while (t_stop <= 1 / opt.tol) t_stop *= kappa0;
+  if (early_stop_col_ >= P_.K) throw ArgError("amgb: early-stop column out of range");
+  const bool fixed = !opt.upstream_stop;
+  auto going = [&](double tt) { return fixed ? tt < t_stop : tt <= 1 / opt.tol; };
+  // centres that are the answer (the last t), or may become it (early stop), are resolved; the others only followed
+  auto final_at = [&](double tt) { return opt.exact_centering || early_stop_col_ >= 0 || !going(tt); };
   {
     // initial centering: repeat from the improved iterate (oracle INITIAL_CENTERING_ATTEMPTS)
     bool ok0 = false;
     for (int attempt = 0; attempt < kInitialCenteringAttempts && !ok0; ++attempt)
-      ok0 = amgb_step(t, lam_tol, opt.max_newton, its, st, opt.verbose);
+      ok0 = amgb_step(t, final_at(t), lam_tol, opt.max_newton, its, st, opt.verbose);
     if (!ok0) throw NumericError("amgb: initial centering failed");
   }
   st.its.insert(st.its.end(), its.begin(), its.end());
   st.ts.push_back(t);
   st.c_dot_Dz.push_back(c_dot_dz());
   int k = 1;
-  // the continuation ends at a FIXED t: the first value of the nominal sequence t0 kappa0^k beyond 1 / tol (oracle amgb_core:
-  // otherwise the last t, and with it z to ~1e-6, depends on the rounding-sensitive history of kappa reductions)
-  double t_stop = t;
-  while (t_stop <= 1 / opt.tol) t_stop *= kappa0;
-  if (early_stop_col_ >= P_.K) throw ArgError("amgb: early-stop column out of range");
   bool stopped = early_stop_col_ >= 0 && slack_negative();
-  const bool fixed = !opt.upstream_stop;
-  auto going = [&](double tt) { return fixed ? tt < t_stop : tt <= 1 / opt.tol; };
   while (going(t) && kappa > 1 && k < opt.maxit && !stopped) {
     k++;
     std::fill(its.begin(), its.end(), 0);
@@ -1248,7 +1253,12 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
       hip_check(hipMemcpyAsync(z_save_.p, z_.p, zbytes, hipMemcpyDeviceToDevice, ctx_.stream), "save z");
       hip_check(hipMemcpyAsync(Dz0_save_.p, Dz0_.p, dzbytes, hipMemcpyDeviceToDevice, ctx_.stream), "save Dz0");
       std::vector<long long> it1(L, 0);
-      bool ok = amgb_step(t1, lam_tol, opt.max_newton, it1, st, opt.verbose);
+      bool ok = amgb_step(t1, final_at(t1), lam_tol, opt.max_newton, it1, st, opt.verbose);
+      // the last centre is resolved from a point that was only followed: it may take more than one Newton budget, as the
+      // initial centering may (oracle amgb_core)
+      if (!going(t1) && !opt.exact_centering && early_stop_col_ < 0)
+        for (int attempt = 0; attempt < kInitialCenteringAttempts - 1 && !ok; ++attempt)
+          ok = amgb_step(t1, true, lam_tol, opt.max_newton, it1, st, opt.verbose);
       long long mx = 0;
       for (int l = 0; l < L; ++l) {
         its[l] += it1[l];

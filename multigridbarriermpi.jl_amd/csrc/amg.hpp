@@ -201,6 +201,7 @@ enum KernelClass {
 constexpr double kFracToBoundary = 0.1;   // == oracle FRAC_TO_BOUNDARY
 constexpr double kKappaGrowFrac = 0.25;   // == oracle KAPPA_GROW_FRAC
 constexpr int kInitialCenteringAttempts = 8;   // == oracle INITIAL_CENTERING_ATTEMPTS
+constexpr double kDecrementFrac = 0.01;        // == oracle DECREMENT_FRAC
 
 struct SolveOptions {
   bool host_solve = false;              // true: factor/solve on the host (MfChol), false: on the GPU (GpuChol)
@@ -211,6 +212,11 @@ struct SolveOptions {
   // t0 kappa^k beyond 1 / tol, last step clipped (end point independent of the history of kappa reductions); true = the literal
   // loop `while t <= 1 / tol: t <- kappa t`.  Same ts whenever kappa is never reduced.
   bool upstream_stop = false;
+  // Newton on the finest level at the intermediate t: true (default) = stagnation of the objective at every t; false = stop once
+  // the decrement <g, n> is below kDecrementFrac min w (the path is followed, not resolved) and keep the stagnation rule for the
+  // last t, whose centre is the answer (oracle CENTERING; fewer Newton steps at p > 1, more at p = 1: profiles/r3_centering_counts.txt).
+  // Phases with an early stop resolve every centre.  [UPSTREAM-UNVERIFIED]
+  bool exact_centering = true;
   double tol = 1.4901161193847656e-08;  // sqrt(eps)
   double t0 = 0.1;
   double kappa = 10.0;
@@ -403,8 +409,8 @@ class Amg {
   // single GPU, device solver: factorisation chain, <g, n> (+ pivot flag hand-over) and both speculative trials as ONE
   // hipGraph launch (one per set of buffer pointers; the trial buffers rotate through at most a dozen combinations)
   void launch_step_graph(Level& lv, Trial* spec);
-  NewtonResult newton(int l, double t, bool finest, double lam_tol, int maxit, SolveStats& st, int verbose);
-  bool amgb_step(double t, double lam_tol, int max_newton, std::vector<long long>& its, SolveStats& st, int verbose);
+  NewtonResult newton(int l, double t, bool finest, bool final, double lam_tol, int maxit, SolveStats& st, int verbose);
+  bool amgb_step(double t, bool final, double lam_tol, int max_newton, std::vector<long long>& its, SolveStats& st, int verbose);
   double c_dot_dz();
 
   // ---- multigrid / CG (amg_mg.cpp)

@@ -35,6 +35,7 @@ struct mgb_amg_s {
   bool host_solve = false;
   bool pcg = false;
   bool upstream_stop = false;
+  bool exact_centering = true;
 };
 struct mgb_plan_s {
   LevelPlan plan;
@@ -965,6 +966,12 @@ int mgb_amg_set_stop_rule(mgb_amg a, int upstream) {
     a->upstream_stop = upstream != 0;
   });
 }
+int mgb_amg_set_centering(mgb_amg a, int exact) {
+  return guard([&] {
+    need(a, "null amg");
+    a->exact_centering = exact != 0;
+  });
+}
 int mgb_amg_set_schedule(mgb_amg a, int all_levels) {
   return guard([&] {
     need(a, "null amg");
@@ -979,6 +986,7 @@ int mgb_amg_solve(mgb_amg a, double tol, double t0, double kappa, int maxit, int
     o.host_solve = a->host_solve;
     o.pcg = a->pcg;
     o.upstream_stop = a->upstream_stop;
+    o.exact_centering = a->exact_centering;
     if (tol > 0) o.tol = tol;
     if (t0 > 0) o.t0 = t0;
     if (kappa > 1) o.kappa = kappa;

@@ -722,7 +722,20 @@ def level_schedule(L, schedule=None):
     return [L - 1] if schedule == "fine" else list(range(L))
 
 
-def amgb_step(B: Barrier, M: AMG, z, Dz0, c, maxit, lam_tol, log=None, schedule=None):
+# Newton's stopping rule on the finest level at the intermediate values of t: "exact" (default) = stagnation of the objective at
+# every t; "decrement" = stop as soon as the Newton decrement <g, n> falls below DECREMENT_FRAC min w (the path is followed, not
+# resolved) and keep the stagnation rule for the LAST t, whose centre is the answer.  Both end at the same point (<= 5e-12).
+# Measured (profiles/r3_centering_counts.txt, Newton steps exact / decrement): fem2d L=7 p=1.5 88 / 75, fem3d L=4 104 / 86, but
+# fem2d L=7 p=1 466 / 580 and L=8 p=1 668 / 677 -- at p = 1 the steps go into damped progress towards each centre, not into
+# resolving it, and starting the next t from a looser point costs more than it saves: hence the default.  [UPSTREAM-UNVERIFIED]
+CENTERING = "exact"
+# threshold of the decrement rule on the finest level, as a fraction of min w: w F is self-concordant only after division by w, so
+# "Newton converges quadratically from here" means <g, n> / min w below a small constant.  (sqrt(min w) / 2, the coarse levels'
+# lam_tol, is far too loose here: at fem2d L=4, p=1 the decrement idles at 0.0187 < 0.0197 for hundreds of full steps.)
+DECREMENT_FRAC = 0.01
+
+
+def amgb_step(B: Barrier, M: AMG, z, Dz0, c, maxit, lam_tol, log=None, schedule=None, final=True):
     """One centering at fixed t (c already scaled by t): Newton on the subspaces R[J] for J in the level
     schedule, each from s = 0, z += R[J] s.  its[l] = Newton steps on level l (docs/src/guide.md:158
     `sum(SOL_main.its)`).  The literal coarse->fine loop ("all") de-centres the iterate at large t (coarse
@@ -739,7 +752,10 @@ def amgb_step(B: Barrier, M: AMG, z, Dz0, c, maxit, lam_tol, log=None, schedule=
             M.BR[J] = [sp.csr_matrix(Dk @ R) for Dk in M.D]
         pre = (Dz0, M.BR[J])
         s0 = np.zeros(R.shape[1])
-        crit = stopping_exact(0.1) if J == L - 1 else stopping_inexact(lam_tol, 0.5)
+        if J == L - 1:
+            crit = stopping_exact(0.1) if (final or CENTERING == "exact") else stopping_inexact(DECREMENT_FRAC * float(np.min(M.w)), 0.1)
+        else:
+            crit = stopping_inexact(lam_tol, 0.5)
         lg = [] if log is not None else None
         SOL = newton(lambda s, ref: B.f0_phi(s, M.x, M.w, c, R, M.D, z, ref, pre),
                      lambda s: B.f1(s, M.x, M.w, c, R, M.D, z, pre),
@@ -780,8 +796,13 @@ def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max
     # initial centering: a far-away start (e.g. the previous time step of parabolic_solve, which sits next to
     # the cone boundary) may need more than one Newton budget; keep centering from the improved iterate
     it0 = np.zeros(len(M.R), dtype=np.int64)
+    t_stop = t
+    while t_stop <= 1 / tol:
+        t_stop *= kappa0
+    fixed = stop_rule == "fixed"
+    going = (lambda tt: tt < t_stop) if fixed else (lambda tt: tt <= 1 / tol)
     for attempt in range(INITIAL_CENTERING_ATTEMPTS):
-        SOL = amgb_step(B, M, z, Dz0, t * c, max_newton, lam_tol, log, schedule)
+        SOL = amgb_step(B, M, z, Dz0, t * c, max_newton, lam_tol, log, schedule, final=(early_stop is not None) or not going(t))
         it0 += SOL["its"]
         z, Dz0 = SOL["z"], SOL["Dz0"]
         if SOL["converged"]:
@@ -795,18 +816,22 @@ def amgb_core(B: Barrier, M: AMG, z, c, tol, t=0.1, maxit=10000, kappa=10.0, max
     # 1 / tol (1e8 for the defaults).  Without it the last t depends on the history of kappa reductions -- a discrete, rounding
     # sensitive path -- and two correct runs end at different central points (fem2d L=7, p=1: t = 1.0e8 or 1.8e8, z 1e-6 apart).
     # stop_rule = "upstream" keeps the literal loop: continue while t <= 1 / tol, every step t <- kappa t.
-    t_stop = t
-    while t_stop <= 1 / tol:
-        t_stop *= kappa0
-    fixed = stop_rule == "fixed"
-    going = (lambda tt: tt < t_stop) if fixed else (lambda tt: tt <= 1 / tol)
     while going(t) and kappa > 1 and k < maxit and not stopped:
         k += 1
         it_k = np.zeros(len(M.R), dtype=np.int64)
         while kappa > 1:
             t1 = min(kappa * t, t_stop) if fixed else kappa * t
-            SOL = amgb_step(B, M, z, Dz0, t1 * c, max_newton, lam_tol, log, schedule)
+            fin = (early_stop is not None) or not going(t1)      # phases that may stop at any centering resolve every one
+            SOL = amgb_step(B, M, z, Dz0, t1 * c, max_newton, lam_tol, log, schedule, final=fin)
             it_k += SOL["its"]
+            if fin and early_stop is None and CENTERING == "decrement":
+                # the last centre is resolved from a point that was only followed: it may take more than one Newton budget, as the
+                # initial centering may (keep centering from the improved iterate before giving kappa up)
+                for attempt in range(INITIAL_CENTERING_ATTEMPTS - 1):
+                    if SOL["converged"]:
+                        break
+                    SOL = amgb_step(B, M, SOL["z"], SOL["Dz0"], t1 * c, max_newton, lam_tol, log, schedule, final=True)
+                    it_k += SOL["its"]
             if SOL["converged"]:
                 if SOL["its"].max() <= max_newton * KAPPA_GROW_FRAC:
                     kappa = min(kappa0, kappa * kappa)

@@ -790,7 +790,7 @@ def test_end_point_does_not_depend_on_summation_order(M):
     assert len(one) == 1 and float(one[0].rsplit("=", 1)[1]) == 0.0, one
 
 
-@pytest.mark.parametrize("kind,L,p", [("fem1d", 3, 2.0), ("fem2d", 3, 1.5)])
+@pytest.mark.parametrize("kind,L,p", [("fem1d", 4, 2.0), ("fem2d", 3, 1.5)])
 def test_stop_rules_visit_the_nominal_sequence(M, kind, L, p):
     """ADVICE r2 (mgb_amg_set_stop_rule): "upstream" = the literal `while t <= 1/tol: t <- kappa t`, "fixed" = end at the first
     t0 kappa^k beyond 1/tol.  Without a kappa reduction both give ts = t0 kappa^k exactly (SOL_main.ts is an observable of the
@@ -809,3 +809,23 @@ def test_stop_rules_visit_the_nominal_sequence(M, kind, L, p):
     assert np.array_equal(zs["fixed"], zs["upstream"])
     with pytest.raises(ValueError):
         M.fem1d_mpi_solve(L=2, stop_rule="sometimes")
+
+
+@pytest.mark.parametrize("kind,L,p", [("fem2d", 4, 1.5), ("fem2d", 5, 1.0), ("fem3d", 2, 1.0)])
+def test_decrement_centering_matches_oracle_and_the_exact_rule(M, kind, L, p):
+    """intermediate centres followed with the Newton-decrement rule (centering="decrement", oracle CENTERING),
+    the last one resolved: same end point as the default rule and as the oracle run with the same rule."""
+    z_exact = M.mpi_to_native(getattr(M, kind + "_mpi_solve")(L=L, p=p)).z
+    sol = getattr(M, kind + "_mpi_solve")(L=L, p=p, centering="decrement")
+    z = M.mpi_to_native(sol).z
+    assert rel(z, z_exact) < ZTOL
+    saved = O.CENTERING
+    try:
+        O.CENTERING = "decrement"
+        so = getattr(O, kind + "_solve")(L=L, p=p)
+    finally:
+        O.CENTERING = saved
+    assert rel(z, so.z) < ZTOL
+    assert abs(int(sol.SOL_main["its"].sum()) - int(so.SOL_main["its"].sum())) <= max(3, 0.25 * so.SOL_main["its"].sum())
+    with pytest.raises(ValueError):
+        M.fem1d_mpi_solve(L=2, centering="never")

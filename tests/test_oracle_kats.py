@@ -268,3 +268,19 @@ def test_both_continuation_stop_rules_visit_the_nominal_sequence():
     assert np.array_equal(sols["fixed"].z, sols["upstream"].z)
     with pytest.raises(ValueError):
         O.amgb(O.fem1d(2), stop_rule="sometimes")
+
+
+def test_decrement_centering_reaches_the_same_end_point():
+    """VERDICT r2 item 5 (oracle CENTERING / mgb_amg_set_centering): following the path with the Newton-decrement rule and
+    resolving only the last centre ends at the point the exact rule ends at, with fewer Newton steps on this mesh."""
+    saved = O.CENTERING
+    try:
+        O.CENTERING = "exact"
+        a = O.fem2d_solve(L=3, p=1.5)
+        O.CENTERING = "decrement"
+        b = O.fem2d_solve(L=3, p=1.5)
+    finally:
+        O.CENTERING = saved
+    assert np.linalg.norm(a.z - b.z) <= 1e-11 * np.linalg.norm(a.z)
+    assert np.array_equal(a.SOL_main["ts"], b.SOL_main["ts"])
+    assert b.SOL_main["its"].sum() < a.SOL_main["its"].sum()
