@@ -9,7 +9,7 @@
 // barrier F/F1/F2 (src/MultiGridBarrierMPI.jl:161-170), a8 amgb_all_isfinite (src:121-133),
 // a9 dot/.* / column extract (test/test_column_extract.jl:50-66).
 #include "kernels.hpp"
-#include "devutil.hpp"
+#include "kernels_tpl.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -20,61 +20,11 @@ namespace {
 
 
 // ---------------------------------------------------------------- SpMV
-// G lanes cooperate on one row: lane j reads nonzero j, j+G, ... (coalesced across the group and,
-// because consecutive rows are adjacent in CSR storage, across the 64/G rows of a wave); the
-// G partial sums are combined with a fixed-order shuffle tree -> bitwise reproducible.
-constexpr int kSpmvU = 2;   // rows in flight per lane group (memory-level parallelism of the dependent rowptr -> nnz -> x chain)
-template <int G>
-__global__ __launch_bounds__(kBlock) void spmv_kernel(int rows, const int* __restrict__ rowptr,
-                                                       const int* __restrict__ colidx,
-                                                       const double* __restrict__ vals,
-                                                       const double* __restrict__ x, const double* y0, double* y) {
-  const int lane = threadIdx.x % G;
-  const long long stride = (long long)gridDim.x * (kBlock / G);
-  for (long long row0 = (long long)xcd_block(blockIdx.x, gridDim.x) * (kBlock / G) + threadIdx.x / G; row0 < rows;
-       row0 += kSpmvU * stride) {
-    int b[kSpmvU], e[kSpmvU];
-    double acc[kSpmvU], base[kSpmvU];
-#pragma unroll
-    for (int u = 0; u < kSpmvU; ++u) {
-      const long long row = row0 + u * stride;
-      const bool ok = row < rows;
-      b[u] = ok ? rowptr[row] : 0;
-      e[u] = ok ? rowptr[row + 1] : 0;
-      base[u] = (ok && y0 && lane == 0) ? y0[row] : 0.0;
-      acc[u] = 0.0;
-    }
-    // first G nonzeros of every row: all loads of the U rows are independent and issued together
-    int ci[kSpmvU];
-    double va[kSpmvU];
-#pragma unroll
-    for (int u = 0; u < kSpmvU; ++u) {
-      const int k = b[u] + lane;
-      const bool in = k < e[u];
-      ci[u] = in ? colidx[k] : -1;
-      va[u] = in ? vals[k] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < kSpmvU; ++u) acc[u] = (ci[u] >= 0) ? va[u] * x[ci[u]] : 0.0;
-    // longer rows: remaining nonzeros
-#pragma unroll
-    for (int u = 0; u < kSpmvU; ++u)
-      for (int k = b[u] + lane + G; k < e[u]; k += G) acc[u] += vals[k] * x[colidx[k]];
-#pragma unroll
-    for (int u = 0; u < kSpmvU; ++u) {
-      double a = acc[u];
-#pragma unroll
-      for (int o = G / 2; o > 0; o >>= 1) a += __shfl_down(a, o, G);
-      const long long row = row0 + u * stride;
-      if (lane == 0 && row < rows) y[row] = base[u] + a;
-    }
-  }
-}
-
+// y = (y0 ? y0 : 0) + A x: the double instantiation of spmv_kernel_t (kernels_tpl.hpp)
 template <int G>
 void spmv_launch(hipStream_t st, const DevCsr& A, const double* x, const double* y0, double* y) {
   const int grid = grid_for((long long)A.rows * G);     // small problems keep one row per lane group
-  hipLaunchKernelGGL(spmv_kernel<G>, dim3(grid), dim3(kBlock), 0, st, A.rows, A.rowptr, A.colidx, A.vals, x, y0, y);
+  hipLaunchKernelGGL((spmv_kernel_t<G, double>), dim3(grid), dim3(kBlock), 0, st, A.rows, A.rowptr, A.colidx, A.vals, x, y0, y);
 }
 
 // Element-local SpMV (DevElCsr): a workgroup takes kElPerBlock consecutive elements per pass, stages their x entries in LDS
@@ -140,48 +90,7 @@ void spmv_el_launch(hipStream_t st, const DevCsr& A, const DevElCsr& E, const do
 
 
 // ---------------------------------------------------------------- barrier
-constexpr int kMaxK = 8;      // rows of D (capi.cpp rejects larger problems for the barrier kernels)
-
-struct Cone {
-  double q[3];
-  double s, phi, sa;  // sa = s^a
-  bool ok;
-};
-
-__device__ inline double pow_a(double s, double a) {
-  if (a == 2.0) return s * s;
-  if (a == 1.0) return s;
-  return pow(s, a);
-}
-
-__device__ inline Cone load_cone(const ConeSpec& P, const double* dz) {
-  Cone c;
-  if (P.kind == 1) {      // half space: phi = coef . y + off, no slack (s = 1 makes the mu log s term vanish)
-    double phi = P.off;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      c.q[i] = (i < P.nq) ? dz[P.iq[i]] : 0.0;
-      phi += (i < P.nq) ? P.coef[i] * c.q[i] : 0.0;
-    }
-    c.s = 1.0;
-    c.sa = 1.0;
-    c.phi = phi;
-    c.ok = phi > 0.0;
-    return c;
-  }
-  double qq = 0.0;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    c.q[i] = (i < P.nq) ? dz[P.iq[i]] : 0.0;
-    qq += c.q[i] * c.q[i];
-  }
-  c.s = dz[P.is] + (P.is2 >= 0 ? dz[P.is2] : 0.0);
-  c.ok = c.s > 0.0;
-  c.sa = c.ok ? pow_a(c.s, P.a) : -1.0;
-  c.phi = c.sa - qq;
-  c.ok = c.ok && (c.phi > 0.0);
-  return c;
-}
+using Cone = ConeT<double>;      // kernels_tpl.hpp: load_cone<double>, pow_a<double>
 
 // phi_ref (nullable, n x ncones): cone distances of every row at the current iterate; a trial row with
 // phi < frac*phi_ref is treated as infeasible (fraction-to-the-boundary rule of the line search).
@@ -199,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void barrier_f0_kernel(int n, BarrierParams
     const double wq = w[q];
     double F = 0.0;
     for (int ci = 0; ci < P.ncones; ++ci) {
-      Cone k = load_cone(P.cone[ci], dz);
+      Cone k = load_cone<double>(P.cone[ci], dz);
       if (phi_ref && !(k.phi >= frac * phi_ref[q * P.ncones + ci])) k.ok = false;
       if (phi_out) phi_out[q * P.ncones + ci] = k.phi;
       F += k.ok ? (-log(k.phi) - P.cone[ci].mu * log(k.s)) : INFINITY;
@@ -302,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void trial_f0_kernel(int n, int N, BarrierP
       double* phi_out = T.phi_out[pa];
       double F = 0.0;
       for (int ci2 = 0; ci2 < P.ncones; ++ci2) {
-        Cone k = load_cone(P.cone[ci2], dz);
+        Cone k = load_cone<double>(P.cone[ci2], dz);
         if (phi_ref && !(k.phi >= frac * phi_ref[q * P.ncones + ci2])) k.ok = false;
         if (phi_out) phi_out[q * P.ncones + ci2] = k.phi;
         F += k.ok ? (-log(k.phi) - P.cone[ci2].mu * log(k.s)) : INFINITY;
@@ -346,99 +255,6 @@ void trial_launch(hipStream_t st, const DevCsr& B, int n, const BarrierParams& P
 #undef MGB_TRIAL_NA
 }
 
-// register-only helpers: the D-row indices of a cone are run-time data, so rows are picked / updated with
-// unrolled selects instead of dynamically indexed local arrays (which would live in scratch) or global
-// read-modify-writes (which serialise on memory latency)
-__device__ inline double pick3(const double (&q)[3], int i) { return i == 0 ? q[0] : (i == 1 ? q[1] : q[2]); }
-
-__global__ __launch_bounds__(kBlock) void barrier_f1_kernel(int n, BarrierParams P, const double* __restrict__ Dz,
-                                                             const double* __restrict__ w,
-                                                             const double* __restrict__ c, double t,
-                                                             double* __restrict__ v) {
-  for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < n; q += (long long)gridDim.x * kBlock) {
-    const double* dz = Dz + q * P.K;
-    const double* cq = c + q * P.K;
-    const double wq = w[q];
-    double vr[kMaxK];
-#pragma unroll
-    for (int j = 0; j < kMaxK; ++j) vr[j] = (j < P.K) ? wq * (t * cq[j]) : 0.0;
-    for (int ci = 0; ci < P.ncones; ++ci) {
-      const ConeSpec& S = P.cone[ci];
-      Cone k = load_cone(S, dz);
-      if (S.kind == 1) {      // half space: dF/dy_i = -coef_i / phi
-#pragma unroll
-        for (int j = 0; j < kMaxK; ++j) {
-          double add = 0.0;
-#pragma unroll
-          for (int i = 0; i < 3; ++i) add += (i < S.nq && S.iq[i] == j) ? -wq * (S.coef[i] / k.phi) : 0.0;
-          vr[j] += add;
-        }
-        continue;
-      }
-      const double ds = S.a * pow_a(k.s, S.a - 1.0);  // d(s^a)/ds
-      const double gs = wq * (-ds / k.phi - S.mu / k.s);      // same expressions as the oracle (divisions kept)
-#pragma unroll
-      for (int j = 0; j < kMaxK; ++j) {
-        double add = 0.0;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) add += (i < S.nq && S.iq[i] == j) ? wq * (2.0 * k.q[i] / k.phi) : 0.0;
-        add += (S.is == j) ? gs : 0.0;
-        add += (S.is2 == j) ? gs : 0.0;
-        vr[j] += add;
-      }
-    }
-    double* vq = v + q * P.K;
-#pragma unroll
-    for (int j = 0; j < kMaxK; ++j)
-      if (j < P.K) vq[j] = vr[j];
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void barrier_f2_kernel(int n, BarrierParams P, const double* __restrict__ Dz,
-                                                             const double* __restrict__ w, double* __restrict__ Y) {
-  const int nY = P.nY();
-  for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < n; q += (long long)gridDim.x * kBlock) {
-    const double* dz = Dz + q * P.K;
-    double* yq = Y + q * nY;
-    const double wq = w[q];
-    int slot = 0;
-    for (int ci = 0; ci < P.ncones; ++ci) {
-      const ConeSpec& S = P.cone[ci];
-      Cone k = load_cone(S, dz);
-      if (S.kind == 1) {      // half space: d2F = coef coef' / phi^2, upper triangle row-major over its columns
-        const double ip2l = 1.0 / (k.phi * k.phi);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-            if (i < S.nq && j >= i && j < S.nq) yq[slot++] = wq * (S.coef[i] * S.coef[j] * ip2l);
-        continue;
-      }
-      const double a = S.a;
-      const double ds = a * pow_a(k.s, a - 1.0);
-      const double dds = (a == 1.0) ? 0.0 : a * (a - 1.0) * pow_a(k.s, a - 2.0);
-      const double ip = 1.0 / k.phi, ip2 = ip * ip;
-      const double hss = -dds * ip + ds * ds * ip2 + S.mu / (k.s * k.s);
-      // Hessian over (q_0..q_{nq-1}, s); a second slack column repeats the s row/column.  Upper triangle,
-      // row-major, of the nact x nact block; entry (i, j) computed from its indices, no local matrix
-      const int nq = S.nq, nact = S.nact();
-#pragma unroll
-      for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          if (i < nact && j >= i && j < nact) {
-            const int ai = min(i, nq), aj = min(j, nq);
-            double h;
-            if (aj < nq) h = 4.0 * pick3(k.q, ai) * pick3(k.q, aj) * ip2 + (ai == aj ? 2.0 * ip : 0.0);
-            else if (ai < nq) h = -2.0 * pick3(k.q, ai) * ds * ip2;
-            else h = hss;
-            yq[slot++] = wq * h;
-          }
-        }
-    }
-  }
-}
-
 // map_rows of the barrier itself (src:161-170 for the closures MultiGridBarrier builds from a convex set): F per row, and the
 // per-row Hessian in the reference's flattened K x K shape (column (j-1) K + k, test/test_map_rows_compare.jl:73) expanded
 // from the packed slots of barrier_f2_kernel.
@@ -448,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void barrier_rows_F_kernel(int n, BarrierPa
     const double* dz = Dz + q * P.K;
     double F = 0.0;
     for (int ci = 0; ci < P.ncones; ++ci) {
-      Cone k = load_cone(P.cone[ci], dz);
+      Cone k = load_cone<double>(P.cone[ci], dz);
       F += k.ok ? (-log(k.phi) - P.cone[ci].mu * log(k.s)) : INFINITY;
     }
     out[q] = F;
@@ -605,11 +421,11 @@ void launch_barrier_f0(hipStream_t st, int n, BarrierParams P, const double* Dz,
 
 void launch_barrier_f1(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, const double* c,
                        double t, double* v) {
-  hipLaunchKernelGGL(barrier_f1_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, P, Dz, w, c, t, v);
+  hipLaunchKernelGGL(barrier_f1_kernel_t<double>, dim3(grid_for(n)), dim3(kBlock), 0, st, n, P, Dz, w, c, t, v);
 }
 
 void launch_barrier_f2(hipStream_t st, int n, BarrierParams P, const double* Dz, const double* w, double* Y) {
-  hipLaunchKernelGGL(barrier_f2_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, P, Dz, w, Y);
+  hipLaunchKernelGGL(barrier_f2_kernel_t<double>, dim3(grid_for(n)), dim3(kBlock), 0, st, n, P, Dz, w, Y);
 }
 
 void launch_barrier_rows_F(hipStream_t st, int n, BarrierParams P, const double* Dz, double* out) {
