@@ -32,77 +32,28 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def cpu_baseline(L, p, budget_s):
-    """The Newton path of this workload on the HOST cores (`kind = "port"`): the oracle's Newton / line-search loop
-    (oracle/mgb_oracle.py, numpy) on the same mesh with the same driver (oracle amgb_core: t-continuation, finest-level Newton), stopped at the budget, with the two
-    heavy pieces in C++ on all cores the process may use -- the Hessian values through the product's host plan
-    (T vec(Y), one thread) and `A \\ g` through the product's host multifrontal Cholesky (csrc/mfchol.cpp, the
-    `solver="host"` factorisation; worker threads from the affinity mask).  Bounded to ~budget_s of host time."""
+    """The Newton path of this workload on the HOST cores, natively (`kind = "port"`): oracle/cpu/mgb_cpu_newton.cpp, a C++ /
+    OpenMP restatement of the oracle's amgb_core / newton / line search / barrier f0-f1-f2 (pinned against the numpy oracle by
+    tests/test_oracle_kats.py) on all cores the process may use, with the Hessian plan and the multifrontal Cholesky of the
+    product's host code (csrc/amg.cpp build_level_plan, csrc/mfchol.cpp; threaded).  Same mesh, same problem, same stopping
+    rules; stopped after the first centering that ends beyond the budget (~budget_s of host time)."""
     import ctypes as C
-    import numpy as np
-    import scipy.sparse as sp
-    import mgb_oracle as O
-    import mgb_amd as M
-    from mgb_amd import _lib
-    h = C.c_void_p()
-    _lib.call("mgb_fem2d_native", int(L), None, 0, C.byref(h))
-    plan, chol = C.c_void_p(), C.c_void_p()
-    try:
-        g = M._native_from_handle(h, "fem2d", ("id", "dx", "dy"))
-        idx = (C.c_int * 2)(1, 2)
-        _lib.call("mgb_plan_create", h, 2, _lib.str_array(M.DEFAULT_STATE), 4, _lib.str_array(M.DEFAULT_D[2]), 2, idx, 3,
-                  int(L) - 1, C.byref(plan))
-        _lib.call("mgb_plan_hostchol_create", plan, 2, C.byref(chol))
-        nthreads = C.c_int()
-        _lib.call("mgb_hostchol_info", chol, None, C.byref(nthreads), None)
-        N, nnz = C.c_int(), C.c_int()
-        _lib.call("mgb_plan_sizes", plan, C.byref(N), C.byref(nnz), None, None)
-        Mo = O.amg(g)                                   # R, D in the C++ builder's dof numbering (the plan's)
-        x, w = Mo.x, Mo.w
-        n = x.shape[0]
-        z = O.map_rows(lambda xi: O.DEFAULT_G[2](xi), x).reshape(-1, order="F")
-        c = O.map_rows(lambda xi: O.DEFAULT_F[2](xi), x)
-        Q = O.convex_Euclidian_power([1, 2, 3], p)
-        B = O.Barrier(Q)
-        assert Mo.R[-1].shape[1] == N.value
-        act = [1, 2, 3]                                 # active D rows of the cone: (q_1, q_2, s); slots (a <= b) row-major
-        vals, nstep = np.empty(nnz.value), np.empty(N.value)
-
-        class HostBarrier(O.Barrier):               # f2 -> lower-triangle values of R'HR in the plan's pattern order
-            def f2(self, s, x_, w_, c_, R_, D_, z0, pre=None):
-                H = self.Q.F2(x_, self._Dz(s, R_, D_, z0, pre))
-                Y = np.stack([w_ * H[:, act[a], act[b]] for a in range(3) for b in range(a, 3)], axis=1)
-                _lib.call("mgb_plan_eval_host", plan, _lib.dptr(_lib.f64(Y)), _lib.dptr(vals))
-                return vals
-
-        def solve(Hvals, grad):
-            gg = _lib.f64(grad)
-            _lib.call("mgb_hostchol_factor_solve", chol, _lib.dptr(Hvals), _lib.dptr(gg), _lib.dptr(nstep))
-            return nstep.copy()
-
-        saved = O.solve
-        O.solve = solve
-        try:
-            # the oracle's own driver (t-continuation with its kappa rule, finest-level Newton, line search), stopped
-            # after the first centering that ends beyond the budget
-            t0 = time.time()
-            SOL = O.amgb_core(HostBarrier(Q), Mo, z, c, float(np.sqrt(np.finfo(np.float64).eps)),
-                              early_stop=lambda Dz0: time.time() - t0 > budget_s)
-            dt = time.time() - t0
-            steps = int(SOL["its"].sum())
-            t_reached = float(SOL["ts"][-1])
-        finally:
-            O.solve = saved
-        return dict(value=n * steps / dt, unit="DoF/s per Newton step", cores=int(nthreads.value), kind="port",
-                    sample="oracle Newton / line-search loop (numpy, 1 thread) with the Hessian plan and the host multifrontal "
-                           "Cholesky of the product in C++ (%d threads): the first %d Newton steps of the same solve (oracle amgb_core: "
-                           "finest-level schedule, t = 0.1 ... %.3g, stopped after the centering that passed the budget) on fem2d "
-                           "L=%d p=%g, %.1f s of host time" % (nthreads.value, steps, t_reached, L, p, dt))
-    finally:
-        if chol:
-            _lib.call("mgb_hostchol_destroy", chol)
-        if plan:
-            _lib.call("mgb_plan_destroy", plan)
-        _lib.call("mgb_geo_destroy", h)
+    import __graft_entry__ as G
+    lib = C.CDLL(G.build_cpu_port())      # prebuilt by build(); compiled here only if missing or stale
+    dp, ip, lp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_longlong)
+    lib.mgb_cpu_solve.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, dp, lp, dp, dp, ip]
+    steps, sec, t_reached, threads = C.c_longlong(), C.c_double(), C.c_double(), C.c_int()
+    rc = lib.mgb_cpu_solve(2, int(L), 3, float(p), float(budget_s), 0, None, C.byref(steps), C.byref(sec), C.byref(t_reached),
+                           C.byref(threads))
+    if rc != 0:
+        raise RuntimeError("cpu_baseline: the C++ port failed (see stderr)")
+    n = 14 * 4 ** (int(L) - 1)
+    return dict(value=n * steps.value / sec.value, unit="DoF/s per Newton step", cores=int(threads.value), kind="port",
+                sample="C++ / OpenMP restatement of the same Newton path (oracle/cpu/mgb_cpu_newton.cpp: t-continuation, finest-level "
+                       "Newton, line search, barrier f0 / f1 / f2, threaded Hessian plan + host multifrontal Cholesky of the product) "
+                       "on %d host threads: the first %d Newton steps of the same solve (t = 0.1 ... %.3g, stopped after the "
+                       "centering that passed the budget) on fem2d L=%d p=%g, %.1f s of host time"
+                       % (threads.value, steps.value, t_reached.value, L, p, sec.value))
 
 
 def max_over_ranks(elapsed, dist=None, device="cpu"):

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <string>
+#include <thread>
 
 #include "amg.hpp"
 
@@ -1103,7 +1104,20 @@ int mgb_plan_pattern(mgb_plan p, int32_t* rowptr, int32_t* colidx) {
 int mgb_plan_eval_host(mgb_plan p, const double* Y, double* lower_vals) {
   return guard([&] {
     need(p && Y && lower_vals, "null argument");
-    spmv_host(p->plan.T, Y, lower_vals);
+    // rows of T in chunks on the host threads (each value is one row's dot product: same result as the sequential loop)
+    const Csr& T = p->plan.T;
+    const int nthr = std::max(1, std::min(MfChol::threads(), T.rows / 4096));
+    auto rows = [&](int r0, int r1) {
+      for (int r = r0; r < r1; ++r) {
+        double acc = 0;
+        for (int k = T.rowptr[r]; k < T.rowptr[r + 1]; ++k) acc += T.vals[k] * Y[T.colidx[k]];
+        lower_vals[r] = acc;
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthr; ++t) th.emplace_back(rows, (int)((long long)T.rows * t / nthr), (int)((long long)T.rows * (t + 1) / nthr));
+    rows(0, (int)((long long)T.rows / nthr));
+    for (auto& x : th) x.join();
   });
 }
 

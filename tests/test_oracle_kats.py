@@ -284,3 +284,22 @@ def test_decrement_centering_reaches_the_same_end_point():
     assert np.linalg.norm(a.z - b.z) <= 1e-11 * np.linalg.norm(a.z)
     assert np.array_equal(a.SOL_main["ts"], b.SOL_main["ts"])
     assert b.SOL_main["its"].sum() < a.SOL_main["its"].sum()
+
+
+@pytest.mark.parametrize("kind,L,p", [(2, 3, 1.0), (2, 4, 1.5), (1, 4, 2.0), (3, 2, 1.0)])
+def test_cpp_cpu_port_matches_the_numpy_oracle(kind, L, p):
+    """oracle/cpu/mgb_cpu_newton.cpp (bench.py's native cpu_baseline) is pinned to the numpy oracle: same z
+    (1e-10) and about the same Newton count on the default problems in 1-D, 2-D and 3-D."""
+    import ctypes as C
+    import __graft_entry__ as G
+    lib = C.CDLL(G.build_cpu_port())
+    dp, ip, lp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_longlong)
+    lib.mgb_cpu_solve.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, dp, lp, dp, dp, ip]
+    so = getattr(O, "fem%dd_solve" % kind)(L=L, p=p)
+    zo = so.z.reshape(-1, order="F")
+    z = np.zeros(zo.size)
+    steps, sec, tr, th = C.c_longlong(), C.c_double(), C.c_double(), C.c_int()
+    assert lib.mgb_cpu_solve(kind, L, 3, p, 0.0, 2, z.ctypes.data_as(dp), C.byref(steps), C.byref(sec), C.byref(tr), C.byref(th)) == 0
+    assert np.linalg.norm(z - zo) <= 1e-10 * np.linalg.norm(zo)
+    assert tr.value == so.SOL_main["ts"][-1] and th.value == 2
+    assert abs(steps.value - int(so.SOL_main["its"].sum())) <= max(3, 0.25 * so.SOL_main["its"].sum())
