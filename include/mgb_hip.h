@@ -146,6 +146,10 @@ int mgb_amg_create_cones(mgb_ctx ctx, mgb_geo g, int S, const char* const* state
 int mgb_amg_create_terms(mgb_ctx ctx, mgb_geo g, int S, const char* const* state_vars, int K, const char* const* D,
                          int nterms, const int* kind, const int* nq, const int* idx_q, const int* idx_s, const int* idx_s2,
                          const double* p, const double* coef, const double* off, mgb_amg* out);
+/* x-dependent exponent p(x) of power-cone term `term` (upstream convex_Euclidian_power with a function p):
+ * p_nodes[q] = p(x_q) >= 1 at the n (global) nodes; the barrier kernels then use a = 2 / p(x_q) and mu(p(x_q)) per node.
+ * Call after mgb_amg_create*, before the first evaluation. */
+int mgb_amg_set_exponents(mgb_amg a, int term, const double* p_nodes);
 int mgb_amg_destroy(mgb_amg a);
 int mgb_amg_dims(mgb_amg a, int* n, int* S, int* K, int* L, int* nY);   /* n = LOCAL rows on a sharded context */
 int mgb_amg_local_rows(mgb_amg a, int* n_global, int* row0, int* n_local);

@@ -815,8 +815,21 @@ class AMG:
         if cones is None:
             if idx is None:
                 idx = list(range(K - dim - 1, K))       # convex_Euclidian_power(idx=2:dim+2)
-            cones = [(list(idx), float(p))]
+            cones = [(list(idx), float(p) if np.isscalar(p) else p)]      # p may be a function p(x) or per-node values
+        # x-dependent exponents (upstream convex_Euclidian_power with a function p(x)): a callable or an array of per-node values in
+        # a power-cone term is evaluated at the nodes and handed over with mgb_amg_set_exponents after the AMG exists
         self.geometry = geometry
+        node_p, cones = {}, list(cones)
+        for ti, c in enumerate(cones):
+            if c[0] != "linear" and not np.isscalar(c[1]):
+                pv = c[1]
+                pn = (np.array([float(pv(xi)) for xi in geometry.x.to_numpy()]) if callable(pv) else f64(pv).reshape(-1))
+                if pn.size != geometry.x.shape[0] or not np.all(pn >= 1.0):
+                    raise ValueError("p(x) must give one value >= 1 per node")
+                node_p[ti] = pn
+                cones[ti] = (c[0], float(pn[0])) + tuple(c[2:])
+        p = float(p) if np.isscalar(p) else (float(node_p[0][0]) if 0 in node_p else 1.0)
+        self.p_nodes = node_p.get(0)
         self.state_variables, self.D, self.p, self.cones = tuple(state_variables), tuple(D), float(p), list(cones)
         power = [c for c in cones if c[0] != "linear"]
         self.idx = list(power[0][0]) if power else []
@@ -833,6 +846,8 @@ class AMG:
         # n = global rows (what set_c / set_z / get_z exchange on every rank); a sharded AMG (backend.set_comm)
         # evaluates apply_D on its own rows [row0, row0 + n_local) only
         self.n, self.row0, self.n_local = ng.value, r0.value, nl.value
+        for ti, pn in node_p.items():
+            call("mgb_amg_set_exponents", h, int(ti), dptr(pn))
 
     def prepare(self, l=-1):
         """Build the level(s) and the factorisation structures now (default: every level the schedule visits), so
@@ -1196,7 +1211,8 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
                 raise NotImplementedError("amgb: feasibility phase needs the cone's slack to be `id` of a :full variable")
             Dz = M.apply_D_global(M.L - 1, np.zeros(Nf))
             q2 = np.sum(Dz[:, idx[:-1]] ** 2, axis=1)
-            sigma = 1.0 + float(np.max(q2 ** (p / 2.0) - Dz[:, idx[-1]]))
+            pv = M.p_nodes if M.p_nodes is not None else p
+            sigma = 1.0 + float(np.max(q2 ** (pv / 2.0) - Dz[:, idx[-1]]))
             z0[:, names.index(var)] += sigma
             M.set_z(z0.reshape(-1, order="F"))
             if not math.isfinite(M.f0(M.L - 1, np.zeros(Nf), 0.0)):

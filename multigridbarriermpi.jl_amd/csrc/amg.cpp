@@ -559,6 +559,33 @@ void Amg::prepare(int l) {
   }
 }
 
+void Amg::set_exponents(int term, const double* p_nodes) {
+  if (term < 0 || term >= P_.ncones || P_.cone[term].kind != 0) throw ArgError("set_exponents: term is not a power cone");
+  const int nc = P_.ncones;
+  std::vector<double> a((size_t)n_ * nc), mu((size_t)n_ * nc);
+  if (a_node_.n == a.size()) {      // keep what other terms were given
+    hip_check(hipStreamSynchronize(ctx_.stream), "sync");
+    a_node_.download(a.data(), a.size());
+    mu_node_.download(mu.data(), mu.size());
+  } else {
+    for (int q = 0; q < n_; ++q)
+      for (int c = 0; c < nc; ++c) {
+        a[(size_t)q * nc + c] = P_.cone[c].a;
+        mu[(size_t)q * nc + c] = P_.cone[c].mu;
+      }
+  }
+  for (int q = 0; q < n_; ++q) {
+    const double p = p_nodes[r0_ + q];
+    if (!(p >= 1.0) || !std::isfinite(p)) throw ArgError("set_exponents: p(x) must be >= 1 at every node");
+    a[(size_t)q * nc + term] = 2.0 / p;
+    mu[(size_t)q * nc + term] = p == 2.0 ? 0.0 : (p < 2.0 ? 1.0 : 2.0);      // as make_params_cones
+  }
+  a_node_.upload(a.data(), a.size());
+  mu_node_.upload(mu.data(), mu.size());
+  P_.a_node = a_node_.p;
+  P_.mu_node = mu_node_.p;
+}
+
 // c, z arrive / leave in the GLOBAL layout on every rank; a sharded Amg keeps its own rows
 void Amg::set_c(const double* c_host) { c_.upload(c_host + (size_t)r0_ * P_.K, (size_t)n_ * P_.K); }
 

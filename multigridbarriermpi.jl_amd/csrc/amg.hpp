@@ -284,6 +284,9 @@ class Amg {
   // feasibility phases: stop the continuation after the first centering at which row `col` of Dz is negative at every node
   // (col < 0: off).  The solve then returns normally with fewer t-steps instead of running to t_stop.
   void set_early_stop(int col) { early_stop_col_ = col; }
+  // x-dependent exponent of power-cone term `term` (upstream convex_Euclidian_power with a function p(x)):
+  // p_nodes = p at the n_global nodes (>= 1); the barrier kernels then read a = 2 / p and mu(p) per node
+  void set_exponents(int term, const double* p_nodes_global);
   // solver = pcg for prepare() and the fine-grained entry points between solves (solve() takes it from its options)
   void set_pcg(bool on) { pcg_ = on; }
 
@@ -471,7 +474,7 @@ class Amg {
   int early_stop_col_ = -1;
   bool slack_negative();
   DevBuf<float> w32_, c32_, Dz0_32_, Dz32_, v32_, Y32_;      // Float32 shadows of the row data
-  DevBuf<double> rowF_, rowC_;
+  DevBuf<double> rowF_, rowC_, a_node_, mu_node_;
   void ensure_f32(Level& lv);
   BarrierParams P_;
   AmgSpec spec_;

@@ -734,6 +734,12 @@ int mgb_amg_prepare(mgb_amg a, int level) {
     a->amg->prepare(level);
   });
 }
+int mgb_amg_set_exponents(mgb_amg a, int term, const double* p_nodes) {
+  return guard([&] {
+    need(a && p_nodes, "set_exponents: null argument");
+    a->amg->set_exponents(term, p_nodes);
+  });
+}
 int mgb_amg_set_early_stop(mgb_amg a, int col) {
   return guard([&] {
     need(a && col >= -1, "set_early_stop: bad arguments");

@@ -108,10 +108,11 @@ __global__ __launch_bounds__(kBlock) void barrier_f0_kernel(int n, BarrierParams
     const double wq = w[q];
     double F = 0.0;
     for (int ci = 0; ci < P.ncones; ++ci) {
-      Cone k = load_cone<double>(P.cone[ci], dz);
+      const ConeAM<double> am = cone_am<double>(P, ci, q);
+      Cone k = load_cone<double>(P.cone[ci], dz, am.a);
       if (phi_ref && !(k.phi >= frac * phi_ref[q * P.ncones + ci])) k.ok = false;
       if (phi_out) phi_out[q * P.ncones + ci] = k.phi;
-      F += k.ok ? (-log(k.phi) - P.cone[ci].mu * log(k.s)) : INFINITY;
+      F += k.ok ? (-log(k.phi) - am.mu * log(k.s)) : INFINITY;
     }
     accF += wq * F;
     double lin = 0.0;
@@ -211,10 +212,11 @@ __global__ __launch_bounds__(kBlock) void trial_f0_kernel(int n, int N, BarrierP
       double* phi_out = T.phi_out[pa];
       double F = 0.0;
       for (int ci2 = 0; ci2 < P.ncones; ++ci2) {
-        Cone k = load_cone<double>(P.cone[ci2], dz);
+        const ConeAM<double> am = cone_am<double>(P, ci2, q);
+        Cone k = load_cone<double>(P.cone[ci2], dz, am.a);
         if (phi_ref && !(k.phi >= frac * phi_ref[q * P.ncones + ci2])) k.ok = false;
         if (phi_out) phi_out[q * P.ncones + ci2] = k.phi;
-        F += k.ok ? (-log(k.phi) - P.cone[ci2].mu * log(k.s)) : INFINITY;
+        F += k.ok ? (-log(k.phi) - am.mu * log(k.s)) : INFINITY;
       }
       accF += wq * F;
       double lin = 0.0;
@@ -264,8 +266,9 @@ __global__ __launch_bounds__(kBlock) void barrier_rows_F_kernel(int n, BarrierPa
     const double* dz = Dz + q * P.K;
     double F = 0.0;
     for (int ci = 0; ci < P.ncones; ++ci) {
-      Cone k = load_cone<double>(P.cone[ci], dz);
-      F += k.ok ? (-log(k.phi) - P.cone[ci].mu * log(k.s)) : INFINITY;
+      const ConeAM<double> am = cone_am<double>(P, ci, q);
+      Cone k = load_cone<double>(P.cone[ci], dz, am.a);
+      F += k.ok ? (-log(k.phi) - am.mu * log(k.s)) : INFINITY;
     }
     out[q] = F;
   }

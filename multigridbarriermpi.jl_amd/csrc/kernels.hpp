@@ -56,6 +56,10 @@ struct BarrierParams {
   int K = 0;
   int ncones = 1;
   ConeSpec cone[kMaxCones];
+  // x-dependent exponents p(x) of the power cones (upstream convex_Euclidian_power with a function p): per node
+  // and term, a = 2 / p(x_q) and mu(p(x_q)) in device arrays of n x ncones doubles; null = the terms' own constants
+  const double* a_node = nullptr;
+  const double* mu_node = nullptr;
   __host__ __device__ int nY() const {
     int s = 0;
     for (int c = 0; c < ncones; ++c) s += cone[c].nY();

@@ -73,8 +73,21 @@ __device__ inline T pow_a(T s, T a) {
   return pow(s, a);
 }
 
+// exponent data of term ci at node q: the per-node arrays of an x-dependent exponent, or the term's constants
 template <class T>
-__device__ inline ConeT<T> load_cone(const ConeSpec& P, const T* dz) {
+struct ConeAM {
+  T a, mu;
+};
+template <class T>
+__device__ inline ConeAM<T> cone_am(const BarrierParams& P, int ci, long long q) {
+  ConeAM<T> r;
+  r.a = P.a_node ? T(P.a_node[q * P.ncones + ci]) : T(P.cone[ci].a);
+  r.mu = P.mu_node ? T(P.mu_node[q * P.ncones + ci]) : T(P.cone[ci].mu);
+  return r;
+}
+
+template <class T>
+__device__ inline ConeT<T> load_cone(const ConeSpec& P, const T* dz, T a) {
   ConeT<T> c;
   if (P.kind == 1) {
     T phi = T(P.off);
@@ -97,7 +110,7 @@ __device__ inline ConeT<T> load_cone(const ConeSpec& P, const T* dz) {
   }
   c.s = dz[P.is] + (P.is2 >= 0 ? dz[P.is2] : T(0));
   c.ok = c.s > T(0);
-  c.sa = c.ok ? pow_a<T>(c.s, T(P.a)) : T(-1);
+  c.sa = c.ok ? pow_a<T>(c.s, a) : T(-1);
   c.phi = c.sa - qq;
   c.ok = c.ok && (c.phi > T(0));
   return c;
@@ -117,8 +130,9 @@ __global__ __launch_bounds__(kBlock) void barrier_f0_rows_kernel_t(int n, Barrie
     const T* dz = Dz + q * P.K;
     T F = T(0);
     for (int ci = 0; ci < P.ncones; ++ci) {
-      const ConeT<T> k = load_cone<T>(P.cone[ci], dz);
-      F += k.ok ? (-log(k.phi) - T(P.cone[ci].mu) * log(k.s)) : T(INFINITY);
+      const ConeAM<T> am = cone_am<T>(P, ci, q);
+      const ConeT<T> k = load_cone<T>(P.cone[ci], dz, am.a);
+      F += k.ok ? (-log(k.phi) - am.mu * log(k.s)) : T(INFINITY);
     }
     T cd = T(0);
 #pragma unroll
@@ -141,7 +155,8 @@ __global__ __launch_bounds__(kBlock) void barrier_f1_kernel_t(int n, BarrierPara
     for (int j = 0; j < kMaxK; ++j) vr[j] = (j < P.K) ? wq * (t * cq[j]) : T(0);
     for (int ci = 0; ci < P.ncones; ++ci) {
       const ConeSpec& S = P.cone[ci];
-      const ConeT<T> k = load_cone<T>(S, dz);
+      const ConeAM<T> am = cone_am<T>(P, ci, q);
+      const ConeT<T> k = load_cone<T>(S, dz, am.a);
       if (S.kind == 1) {
 #pragma unroll
         for (int j = 0; j < kMaxK; ++j) {
@@ -152,8 +167,8 @@ __global__ __launch_bounds__(kBlock) void barrier_f1_kernel_t(int n, BarrierPara
         }
         continue;
       }
-      const T ds = T(S.a) * pow_a<T>(k.s, T(S.a) - T(1));
-      const T gs = wq * (-ds / k.phi - T(S.mu) / k.s);
+      const T ds = am.a * pow_a<T>(k.s, am.a - T(1));
+      const T gs = wq * (-ds / k.phi - am.mu / k.s);
 #pragma unroll
       for (int j = 0; j < kMaxK; ++j) {
         T add = T(0);
@@ -182,7 +197,8 @@ __global__ __launch_bounds__(kBlock) void barrier_f2_kernel_t(int n, BarrierPara
     int slot = 0;
     for (int ci = 0; ci < P.ncones; ++ci) {
       const ConeSpec& S = P.cone[ci];
-      const ConeT<T> k = load_cone<T>(S, dz);
+      const ConeAM<T> am = cone_am<T>(P, ci, q);
+      const ConeT<T> k = load_cone<T>(S, dz, am.a);
       if (S.kind == 1) {
         const T ip2l = T(1) / (k.phi * k.phi);
 #pragma unroll
@@ -192,11 +208,11 @@ __global__ __launch_bounds__(kBlock) void barrier_f2_kernel_t(int n, BarrierPara
             if (i < S.nq && j >= i && j < S.nq) yq[slot++] = wq * (T(S.coef[i]) * T(S.coef[j]) * ip2l);
         continue;
       }
-      const T a = T(S.a);
+      const T a = am.a;
       const T ds = a * pow_a<T>(k.s, a - T(1));
       const T dds = (a == T(1)) ? T(0) : a * (a - T(1)) * pow_a<T>(k.s, a - T(2));
       const T ip = T(1) / k.phi, ip2 = ip * ip;
-      const T hss = -dds * ip + ds * ds * ip2 + T(S.mu) / (k.s * k.s);
+      const T hss = -dds * ip + ds * ds * ip2 + am.mu / (k.s * k.s);
       const int nq = S.nq, nact = S.nact();
 #pragma unroll
       for (int i = 0; i < 5; ++i)

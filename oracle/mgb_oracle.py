@@ -435,9 +435,11 @@ def amg(geometry: Geometry, state_variables=DEFAULT_STATE, D=None) -> AMG:
 # ----------------------------------------------------------------------------
 
 
-def barrier_mu(p: float) -> float:
-    """log-s multiplicity of the power-cone barrier."""
-    return 0.0 if p == 2 else (1.0 if p < 2 else 2.0)
+def barrier_mu(p):
+    """log-s multiplicity of the power-cone barrier; elementwise for per-node exponents."""
+    if np.isscalar(p):
+        return 0.0 if p == 2 else (1.0 if p < 2 else 2.0)
+    return np.where(p == 2, 0.0, np.where(p < 2, 1.0, 2.0))
 
 
 @dataclass
@@ -508,7 +510,9 @@ class PowerConeBarrier:
 
 
 def convex_Euclidian_power(idx, p) -> PowerConeBarrier:
-    return PowerConeBarrier(tuple(idx), float(p))
+    """p: the exponent, or an array of per-node exponents p(x_q) (upstream accepts a function p(x); callers evaluate it at the
+    nodes): every formula above is elementwise in p."""
+    return PowerConeBarrier(tuple(idx), float(p) if np.isscalar(p) else np.asarray(p, dtype=np.float64))
 
 
 @dataclass
@@ -872,6 +876,8 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
     z0 = map_rows(lambda xi: g(xi), x)           # (n, S)
     c = map_rows(lambda xi: f(xi), x)            # (n, K)
     nD = len(M.D)
+    if callable(p):                              # x-dependent exponent p(x): evaluated at the nodes
+        p = np.array([float(p(xi)) for xi in x])
     Q = convex_Euclidian_power(idx=list(cone_idx) if cone_idx is not None else
                                (list(range(1, dim + 2)) if nD == dim + 2 else list(range(nD - dim - 1, nD))), p=p)
     B = Barrier(ConeIntersection([Q, *extra]) if extra else Q)

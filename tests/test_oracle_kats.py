@@ -303,3 +303,15 @@ def test_cpp_cpu_port_matches_the_numpy_oracle(kind, L, p):
     assert np.linalg.norm(z - zo) <= 1e-10 * np.linalg.norm(zo)
     assert tr.value == so.SOL_main["ts"][-1] and th.value == 2
     assert abs(steps.value - int(so.SOL_main["its"].sum())) <= max(3, 0.25 * so.SOL_main["its"].sum())
+
+
+def test_per_node_exponents_reduce_to_the_scalar_case():
+    """an x-dependent exponent p(x) (upstream convex_Euclidian_power with a function p) enters as per-node a = 2 / p
+    and mu(p); a constant p(x) must reproduce the scalar solve bit for bit, a varying one stays a valid convex problem."""
+    g = O.fem2d(3)
+    n = g.x.shape[0]
+    a, b = O.amgb(g, p=1.5), O.amgb(g, p=np.full(n, 1.5))
+    assert np.array_equal(a.z, b.z)
+    c = O.amgb(g, p=lambda x: 1.5 + 0.4 * x[0])
+    assert np.all(np.isfinite(c.z)) and np.abs(c.z - a.z).max() > 1e-3
+    assert np.array_equal(O.barrier_mu(np.array([1.0, 2.0, 3.0])), np.array([1.0, 0.0, 2.0]))
