@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <thread>
+#include <string>
 #include <cstdlib>
 #include <cstdio>
 
@@ -184,8 +185,50 @@ Csr build_dstack(const GeometryHost& g, const AmgSpec& spec) {
   return D;
 }
 
+// the row / pair enumeration shared by the pattern pass and the term pass of the Hessian plan
+namespace {
+struct RowU {
+  std::vector<int> cols;
+  std::vector<double> val;     // nact x ncols
+  std::vector<char> present;   // nact x ncols
+};
+void gather_row(const Csr& B, int K, int q, const ConeSpec& S, RowU& u) {
+  const int nact = S.nact();
+  u.cols.clear();
+  for (int a = 0; a < nact; ++a) {
+    const int r = q * K + S.col(a);
+    for (int e = B.rowptr[r]; e < B.rowptr[r + 1]; ++e) u.cols.push_back(B.colidx[e]);
+  }
+  std::sort(u.cols.begin(), u.cols.end());
+  u.cols.erase(std::unique(u.cols.begin(), u.cols.end()), u.cols.end());
+  const int nc = (int)u.cols.size();
+  u.val.assign((size_t)nact * nc, 0.0);
+  u.present.assign((size_t)nact * nc, 0);
+  for (int a = 0; a < nact; ++a) {
+    const int r = q * K + S.col(a);
+    for (int e = B.rowptr[r]; e < B.rowptr[r + 1]; ++e) {
+      const int j = (int)(std::lower_bound(u.cols.begin(), u.cols.end(), B.colidx[e]) - u.cols.begin());
+      u.val[(size_t)a * nc + j] += B.vals[e];
+      u.present[(size_t)a * nc + j] = 1;
+    }
+  }
+}
+inline bool structural_pair(const RowU& u, int nc, int a, int b, int i, int j) {
+  return (u.present[(size_t)a * nc + i] && u.present[(size_t)b * nc + j]) ||
+         (a != b && u.present[(size_t)b * nc + i] && u.present[(size_t)a * nc + j]);
+}
+template <class Fn>
+void node_chunks(int n, int nthr, Fn&& fn) {      // fn(q_lo, q_hi, thread)
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthr; ++t)
+    th.emplace_back([&, t] { fn((int)((long long)n * t / nthr), (int)((long long)n * (t + 1) / nthr), t); });
+  fn(0, (int)((long long)n / nthr), 0);
+  for (auto& x : th) x.join();
+}
+}  // namespace
+
 LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr& Dstack, int level,
-                           const BarrierParams& P) {
+                           const BarrierParams& P, bool with_T) {
   static const bool vt = std::getenv("MGB_VERBOSE_SETUP") != nullptr;
   double tph = now_s();
   auto phase = [&](const char* what) {
@@ -231,47 +274,12 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
   phase("R, B = D R, B'");
   // Hessian plan: A = sum_q sum_cones sum_{a<=b} Y[q, base_c + slot(a,b)] * (B_a[q,:]' B_b[q,:] + sym), lower
   // triangle only; a, b run over the cone's active D rows (ConeSpec::col)
-  const int nY = P.nY();
-  struct RowU {
-    std::vector<int> cols;
-    std::vector<double> val;     // nact x ncols
-    std::vector<char> present;   // nact x ncols
-  };
-  auto gather = [&](int q, const ConeSpec& S, RowU& u) {
-    const int nact = S.nact();
-    u.cols.clear();
-    for (int a = 0; a < nact; ++a) {
-      const int r = q * K + S.col(a);
-      for (int e = pl.B.rowptr[r]; e < pl.B.rowptr[r + 1]; ++e) u.cols.push_back(pl.B.colidx[e]);
-    }
-    std::sort(u.cols.begin(), u.cols.end());
-    u.cols.erase(std::unique(u.cols.begin(), u.cols.end()), u.cols.end());
-    const int nc = (int)u.cols.size();
-    u.val.assign((size_t)nact * nc, 0.0);
-    u.present.assign((size_t)nact * nc, 0);
-    for (int a = 0; a < nact; ++a) {
-      const int r = q * K + S.col(a);
-      for (int e = pl.B.rowptr[r]; e < pl.B.rowptr[r + 1]; ++e) {
-        const int j = (int)(std::lower_bound(u.cols.begin(), u.cols.end(), pl.B.colidx[e]) - u.cols.begin());
-        u.val[(size_t)a * nc + j] += pl.B.vals[e];
-        u.present[(size_t)a * nc + j] = 1;
-      }
-    }
-  };
-  auto structural = [&](const RowU& u, int nc, int a, int b, int i, int j) {
-    return (u.present[(size_t)a * nc + i] && u.present[(size_t)b * nc + j]) ||
-           (a != b && u.present[(size_t)b * nc + i] && u.present[(size_t)a * nc + j]);
-  };
+  auto gather = [&](int q, const ConeSpec& S, RowU& u) { gather_row(pl.B, K, q, S, u); };
+  auto structural = [&](const RowU& u, int nc, int a, int b, int i, int j) { return structural_pair(u, nc, a, b, i, j); };
   // Both passes run over node chunks on the host threads (MfChol::threads(): affinity mask, at most 16); every result is
   // assembled in node order, so the plan is identical to the sequential one.
   const int nthr = std::max(1, std::min(MfChol::threads(), n / 2048));
-  auto chunks = [&](auto&& fn) {      // fn(q_lo, q_hi, thread)
-    std::vector<std::thread> th;
-    for (int t = 1; t < nthr; ++t)
-      th.emplace_back([&, t] { fn((int)((long long)n * t / nthr), (int)((long long)n * (t + 1) / nthr), t); });
-    fn(0, (int)((long long)n / nthr), 0);
-    for (auto& x : th) x.join();
-  };
+  auto chunks = [&](auto&& fn) { node_chunks(n, nthr, fn); };
   // pass A: pattern (lower triangle of R'HR): per chunk sorted + unique keys, then one sort of the (already small) union
   std::vector<std::vector<unsigned long long>> tkeys(nthr);
   chunks([&](int q0, int q1, int tI) {
@@ -322,6 +330,20 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
     pl.Apat.colidx[e] = (int)(keys[e] & 0xffffffffu);
   }
   for (int r = 0; r < pl.N; ++r) pl.Apat.rowptr[r + 1] += pl.Apat.rowptr[r];
+  if (with_T) {
+    build_plan_terms(pl, n, P);
+    phase("terms of T");
+  }
+  return pl;
+}
+
+void build_plan_terms(LevelPlan& pl, int n, const BarrierParams& P) {
+  const int K = P.K, nY = P.nY();
+  auto gather = [&](int q, const ConeSpec& S, RowU& u) { gather_row(pl.B, K, q, S, u); };
+  auto structural = [&](const RowU& u, int nc, int a, int b, int i, int j) { return structural_pair(u, nc, a, b, i, j); };
+  const int nthr = std::max(1, std::min(MfChol::threads(), n / 2048));
+  auto chunks = [&](auto&& fn) { node_chunks(n, nthr, fn); };
+  auto phase = [](const char*) {};
   auto entry = [&](int r, int c) {
     const int* b0 = pl.Apat.colidx.data() + pl.Apat.rowptr[r];
     const int* e0 = pl.Apat.colidx.data() + pl.Apat.rowptr[r + 1];
@@ -394,7 +416,6 @@ LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr
     std::vector<Term>().swap(tterms[tI]);
   });
   phase("fill terms");
-  return pl;
 }
 
 // ------------------------------------------------------------------ Amg
@@ -489,7 +510,12 @@ Amg::Level& Amg::level(int l) {
   Level& lv = *levels_.at(l);
   if (lv.built) return lv;
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
-  lv.plan = build_level_plan(geo_, spec_, dstack_host_, l, P_);
+  // single GPU with element-local operators: the Newton matrix is assembled element by element (DevElAsmOwned) and the plan T is
+  // only built if something asks for it (ensure_T); sharded jobs and geometries without element blocks keep T
+  static const bool use_elasm = !(std::getenv("MGB_ASSEMBLE") && std::string(std::getenv("MGB_ASSEMBLE")) == "plan");
+  const bool try_elasm = use_elasm && ctx_.world == 1 && geo_.block > 1 && n_ % geo_.block == 0;
+  lv.plan = build_level_plan(geo_, spec_, dstack_host_, l, P_, /*with_T=*/!try_elasm);
+  lv.T_built = !try_elasm;
   if (ctx_.world > 1) {
     std::vector<unsigned long long> mask = dof_rank_masks(lv.plan.B, ng_, P_.K, ctx_.world, geo_.block);
     lv.plan = shard_level_plan(lv.plan, ng_, S_, P_.K, P_.nY(), r0_, r0_ + n_);
@@ -502,7 +528,12 @@ Amg::Level& Amg::level(int l) {
   // nonzero); launch-bound ones (the fused objective kernel's regime) never use it
   if (n_ > fused_trial_rows_ && geo_.block > 1 && n_ % geo_.block == 0) lv.Bel.build(lv.plan.B, geo_.block * P_.K);
   lv.BT.upload(lv.plan.BT);
-  lv.T.upload(lv.plan.T);
+  if (lv.T_built) lv.T.upload(lv.plan.T);
+  if (try_elasm && lv.plan.N > 0) {
+    mg_of(lv);
+    if (mg_ensure_elop(lv)) lv.elasm.build(lv.mg->elop, lv.plan.Apat, P_);
+    if (!lv.elasm.view.valid()) ensure_T(lv);
+  }
   const int N = lv.plan.N, nnzA = lv.plan.Apat.nnz();
   lv.s.alloc(N);
   lv.s_trial.alloc(N);
@@ -537,6 +568,36 @@ void Amg::ensure_chol(Level& lv) {
   lv.gchol.build(lv.chol, &ctx_);      // sharded context: split by subtrees (gpuchol.hpp)
   if (vt) std::fprintf(stderr, "[mgb setup] gpuchol build + upload      %.3f s\n", now_s() - t0);
   lv.chol_built = true;
+}
+
+static double csr_bytes(const DevCsr& A, bool y0);
+
+void Amg::ensure_T(Level& lv) {
+  if (!lv.T_built) {
+    build_plan_terms(lv.plan, ng_, P_);
+    lv.T_built = true;
+  }
+  if (lv.T.view.rows == 0 && lv.plan.T.rows > 0) {
+    hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
+    lv.T.upload(lv.plan.T);
+  }
+}
+
+double Amg::assemble_bytes(Level& lv) {
+  if (!lv.elasm.view.valid()) return csr_bytes(lv.T.view, false);
+  const DevElOp& E = lv.mg->elop.view;
+  // element pass: values + Y + class ids read, element matrices written; gather: element matrices + lists read, values written
+  return (double)lv.B.view.nnz * 8 + (double)n_ * P_.nY() * 8 + E.nel * 4.0 + 2.0 * E.nel * lv.elasm.view.npm * 8 +
+         (double)E.nel * lv.elasm.view.npm * 4 + lv.plan.Apat.nnz() * 12.0;
+}
+
+void Amg::assemble_values(Level& lv) {
+  if (lv.elasm.view.valid()) {
+    launch_elop_assemble(ctx_.stream, lv.mg->elop.view, lv.elasm.view, P_, Y_.p, lv.elasm.elmat.p, lv.avals.p);
+    return;
+  }
+  ensure_T(lv);
+  launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
 }
 
 const LevelPlan& Amg::plan(int l) { return level(l).plan; }
@@ -766,8 +827,8 @@ void Amg::enqueue_f2_assemble(Level& lv, const double* dz, SolveStats& st) {
     st.n_f2++;
     return;
   }
-  timer_.begin(ctx_.stream, KC_ASSEMBLE, csr_bytes(lv.T.view, false));
-  launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
+  timer_.begin(ctx_.stream, KC_ASSEMBLE, assemble_bytes(lv));
+  assemble_values(lv);
   timer_.end(ctx_.stream);
   // sharded: summed over the row blocks, unless the factorisation's subtrees follow the row partition -- then a rank's own
   // contributions are all its subtree needs and the few entries among separator unknowns travel inside the solve
@@ -913,7 +974,7 @@ bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, do
         st.pcg_gaveup_at = st.n_factor;
       }
       ensure_chol(lv);
-      launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
+      assemble_values(lv);
       lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g.p, lv.nstep.p, nullptr, false);
       lv.flag_armed = false;
       hip_check(hipMemcpyAsync(h_flag_.p, lv.gchol.fail_flag(), sizeof(int), hipMemcpyDeviceToHost, ctx_.stream), "D2H flag");
@@ -1345,7 +1406,7 @@ void Amg::f2(int l, const double* s_host, double t, double* avals_host) {
   lv.s_trial.upload(s_host, lv.plan.N);
   dev_apply(lv, lv.s_trial.p, Dz_.p);
   launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p);
-  launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
+  assemble_values(lv);
   ctx_.allreduce_sum(lv.avals.p, lv.plan.Apat.nnz());
   hip_check(hipStreamSynchronize(ctx_.stream), "sync f2");
   lv.avals.download(avals_host, lv.plan.Apat.nnz());
@@ -1368,6 +1429,7 @@ void Amg::ensure_f32(Level& lv) {
   launch_to_f32(ctx_.stream, n_, w_.p, w32_.p);
   launch_to_f32(ctx_.stream, (long long)nK, c_.p, c32_.p);
   launch_to_f32(ctx_.stream, (long long)nK, Dz0_.p, Dz0_32_.p);
+  ensure_T(lv);
   if (!lv.f32_built) {
     lv.B32.alloc(lv.B.view.nnz);
     lv.BT32.alloc(lv.BT.view.nnz);
@@ -1439,6 +1501,7 @@ void Amg::f2_tpl64(int l, const double* s_host, double t, double* avals_host) {
   if (ctx_.world > 1) throw ArgError("f2_tpl64: single-GPU contexts only");
   Level& lv = level(l);
   lv.s_trial.upload(s_host, lv.plan.N);
+  ensure_T(lv);
   launch_spmv_tpl_f64(ctx_.stream, lv.B.view, lv.s_trial.p, Dz0_.p, Dz_.p);
   launch_barrier_f2_tpl_f64(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p);
   launch_spmv_tpl_f64(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
@@ -1485,6 +1548,7 @@ bool Amg::solve_host(int l, const double* avals, const double* g, double* nstep)
 // (FETCH_SIZE counts Infinity-Cache hits too, MI355X_MICROARCH.md).
 Amg::KernelTimes Amg::time_kernels(int l, int reps, int nrot) {
   Level& lv = level(l);
+  ensure_T(lv);      // the probe times the plan product T vec(Y) as well
   KernelTimes kt{};
   if (nrot < 1) nrot = 1;
   hipEvent_t e0, e1;

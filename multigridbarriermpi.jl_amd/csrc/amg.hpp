@@ -127,6 +127,21 @@ struct DevElOpOwned {
   DevBuf<unsigned long long> c_ent;
   // block = nodes per element, K = rows of D: rows [e block K, (e + 1) block K) of B form element e
   bool build(const Csr& B, const DevCsr& Bdev, int block, int K, int nY);
+  // host copies the element-slab assembly is built from (released by build_assembly)
+  std::vector<int> h_ecols, h_cls;
+  std::vector<unsigned short> h_tptr;
+  std::vector<unsigned long long> h_ent;
+};
+
+// Owning element-slab assembly plan (mg.hpp: DevElAsm) on top of an element operator: pair lists per structure class, the gather
+// lists of the lower-triangle pattern, the element-matrix scratch.  Replaces the Hessian plan T (46 MB at fem2d L=7, 736 MB at L=9).
+struct DevElAsmOwned {
+  DevElAsm view;
+  DevBuf<int> c_npairs, c_tptr, aptr, aidx;
+  DevBuf<unsigned long long> c_terms;
+  DevBuf<double> elmat;
+  // false (and invalid) if a pair of the elements falls outside the pattern -- the caller then keeps the plan T
+  bool build(DevElOpOwned& E, const Csr& Apat, const BarrierParams& P);
 };
 
 // Host-side symbolic pieces of the multigrid hierarchy (testable without a GPU)
@@ -188,8 +203,11 @@ Csr shard_dstack(const Csr& Dstack, int n, int S, int K, int r0, int r1);
 size_t reduction_scratch_doubles(int n_local, int max_level_unknowns);
 
 Csr build_dstack(const GeometryHost& g, const AmgSpec& spec);
+// with_T = false leaves T empty: levels that assemble their Newton matrix element by element (DevElAsmOwned) never need it;
+// build_plan_terms fills it in later if a consumer (Float32 evaluation, sharded jobs, host-only tests) asks
 LevelPlan build_level_plan(const GeometryHost& g, const AmgSpec& spec, const Csr& Dstack, int level,
-                           const BarrierParams& P);
+                           const BarrierParams& P, bool with_T = true);
+void build_plan_terms(LevelPlan& pl, int n, const BarrierParams& P);
 
 // kernel classes timed live with HIP events (KernelTimer) on every 8th Newton step (bracketing every launch
 // costs ~14 % of a solve)
@@ -328,7 +346,8 @@ class Amg {
 
  private:
   struct Level {
-    bool built = false, chol_built = false;
+    bool built = false, chol_built = false, T_built = false;
+    DevElAsmOwned elasm;      // element-slab assembly (single-GPU contexts with element-local operators)
     bool flag_armed = false;      // the pivot flag of gchol is known to be zero (re-armed by the dot kernel of the last solve)
     // captured Newton-step graphs (factorisation chain + <g, n> + both speculative trials), one per set of buffer pointers
     struct StepGraph {
@@ -368,6 +387,10 @@ class Amg {
   Level& level(int l);            // lazily built
   int level_index(const Level& lv) const;
   void ensure_chol(Level& lv);    // factorisation structures, built on first solve
+  void ensure_T(Level& lv);       // the Hessian plan T on the device (lazily: only levels without an element-slab assembly, Float32, probes)
+  // lower-triangle values of the level's Newton matrix from Y_ into lv.avals: element-slab assembly, or T vec(Y)
+  void assemble_values(Level& lv);
+  double assemble_bytes(Level& lv);
   void refresh_dz0();
   void dev_apply(Level& lv, const double* s_dev, double* dz);     // dz = Dz0 + B s
   // objective at x = s_dev + alpha * nstep (nstep nullable: x = s_dev); leaves D(z + R x) in dz and x in s_out

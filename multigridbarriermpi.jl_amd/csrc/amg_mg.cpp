@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <map>
 #include <string>
+#include <thread>
 
 #include "amg.hpp"
 
@@ -101,6 +102,10 @@ bool DevElOpOwned::build(const Csr& B, const DevCsr& Bdev, int block, int K, int
     for (int e = 0; e < nel; ++e)
       for (int j = 0; j < (int)cols[e].size(); ++j) didx[pos[cols[e][j]]++] = e * cmax + j;
   }
+  h_ecols = ec;
+  h_cls = cls;
+  h_tptr = c_tptr;
+  h_ent = c_ent;
   this->ecols.upload(ec.data(), ec.size());
   this->cls.upload(cls.data(), cls.size());
   this->dptr.upload(dptr.data(), dptr.size());
@@ -127,6 +132,142 @@ bool DevElOpOwned::build(const Csr& B, const DevCsr& Bdev, int block, int K, int
   view.c_ent = this->c_ent.p;
   view.dptr = this->dptr.p;
   view.didx = this->didx.p;
+  return true;
+}
+
+bool DevElAsmOwned::build(DevElOpOwned& EO, const Csr& Apat, const BarrierParams& P) {
+  view = DevElAsm();
+  const DevElOp& E = EO.view;
+  if (!E.valid() || EO.h_cls.empty()) return false;
+  const int K = E.K, cmax = E.cmax, nzm = E.nnz_max, ncls = E.ncls, blk = E.block;
+  // rows a that some barrier term couples with rows b: act[a] = bit mask of the b (pairs of active rows of one term)
+  unsigned act[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int ci = 0; ci < P.ncones; ++ci) {
+    unsigned m = 0;
+    for (int a = 0; a < P.cone[ci].nact(); ++a) m |= 1u << P.cone[ci].col(a);
+    for (int a = 0; a < P.cone[ci].nact(); ++a) act[P.cone[ci].col(a)] |= m;
+  }
+  // Y entry of (a1, a2) per barrier term: slot of the pair inside the term's packed upper triangle, or -1
+  int yslot[kMaxCones][8][8];
+  {
+    int base = 0;
+    for (int ci = 0; ci < kMaxCones; ++ci)
+      for (int a = 0; a < 8; ++a)
+        for (int b = 0; b < 8; ++b) yslot[ci][a][b] = -1;
+    for (int ci = 0; ci < P.ncones; ++ci) {
+      const ConeSpec& S = P.cone[ci];
+      int slot = base;
+      for (int a = 0; a < S.nact(); ++a)
+        for (int b = a; b < S.nact(); ++b, ++slot) yslot[ci][S.col(a)][S.col(b)] = yslot[ci][S.col(b)][S.col(a)] = slot;
+      base += S.nY();
+    }
+  }
+  const int nY = P.nY();
+  if ((long long)blk * nY > 65535) return false;
+  // per class: the lower-triangle pairs (i >= j) of local columns that share a node on coupled rows, and for each pair its
+  // products (entry of column i, entry of column j on the same node, Y entry)
+  std::vector<std::vector<unsigned short>> pairs(ncls);
+  std::vector<std::vector<int>> tptr(ncls);
+  std::vector<std::vector<unsigned long long>> terms(ncls);
+  int npm = 0, ntm = 0;
+  for (int c = 0; c < ncls; ++c) {
+    const unsigned short* tp = EO.h_tptr.data() + (size_t)c * (cmax + 1);
+    const unsigned long long* ent = EO.h_ent.data() + (size_t)c * nzm;
+    tptr[c].push_back(0);
+    for (int i = 0; i < cmax; ++i)
+      for (int j = 0; j <= i; ++j) {
+        const size_t before = terms[c].size();
+        for (int p1 = tp[i]; p1 < tp[i + 1]; ++p1) {
+          const int k1 = (int)(ent[p1] & 0xffffu), r1 = (int)((ent[p1] >> 16) & 0xffffu), node = r1 / K, a1 = r1 % K;
+          for (int p2 = tp[j]; p2 < tp[j + 1]; ++p2) {
+            const int k2 = (int)(ent[p2] & 0xffffu), r2 = (int)((ent[p2] >> 16) & 0xffffu);
+            if (r2 / K != node) continue;
+            for (int ci = 0; ci < P.ncones; ++ci) {
+              const int sl = yslot[ci][a1][r2 % K];
+              if (sl >= 0)
+                terms[c].push_back((unsigned long long)k1 | (unsigned long long)k2 << 16 | (unsigned long long)(node * nY + sl) << 32);
+            }
+          }
+        }
+        if (terms[c].size() > before) {
+          pairs[c].push_back((unsigned short)(i | j << 8));
+          tptr[c].push_back((int)terms[c].size());
+        }
+      }
+    npm = std::max(npm, (int)pairs[c].size());
+    ntm = std::max(ntm, (int)terms[c].size());
+  }
+  (void)act;
+  if (npm == 0) return false;
+  std::vector<int> cn(ncls), ctp((size_t)ncls * (npm + 1), 0);
+  std::vector<unsigned long long> cte((size_t)ncls * ntm, 0ull);
+  for (int c = 0; c < ncls; ++c) {
+    cn[c] = (int)pairs[c].size();
+    std::copy(tptr[c].begin(), tptr[c].end(), ctp.begin() + (size_t)c * (npm + 1));
+    std::copy(terms[c].begin(), terms[c].end(), cte.begin() + (size_t)c * ntm);
+  }
+  // gather lists: every element slot goes to one lower-triangle entry of the pattern
+  const int nnzA = Apat.nnz();
+  if ((long long)E.nel * npm > 2000000000LL) return false;
+  std::vector<int> tgt((size_t)E.nel * npm, -1), aptr(nnzA + 1, 0);
+  const int nthr = std::max(1, std::min(MfChol::threads(), E.nel / 1024));
+  std::vector<char> bad(nthr, 0);
+  {
+    std::vector<std::thread> th;
+    auto work = [&](int t) {
+      for (int e = (int)((long long)E.nel * t / nthr); e < (int)((long long)E.nel * (t + 1) / nthr); ++e) {
+        const int c = EO.h_cls[e];
+        const int* ec = EO.h_ecols.data() + (size_t)e * cmax;
+        for (int s = 0; s < cn[c]; ++s) {
+          const int I = ec[pairs[c][s] & 0xff], J = ec[pairs[c][s] >> 8];
+          const int* b0 = Apat.colidx.data() + Apat.rowptr[I];
+          const int* e0 = Apat.colidx.data() + Apat.rowptr[I + 1];
+          const int* it = std::lower_bound(b0, e0, J);
+          if (it == e0 || *it != J) {
+            bad[t] = 1;
+            continue;
+          }
+          tgt[(size_t)e * npm + s] = (int)(it - Apat.colidx.data());
+        }
+      }
+    };
+    for (int t = 1; t < nthr; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+  }
+  for (char b : bad)
+    if (b) return false;      // an element pair outside the pattern: keep the plan T
+  for (size_t k = 0; k < tgt.size(); ++k)
+    if (tgt[k] >= 0) aptr[tgt[k] + 1]++;
+  for (int a = 0; a < nnzA; ++a) aptr[a + 1] += aptr[a];
+  std::vector<int> aidx(aptr[nnzA]), pos(aptr.begin(), aptr.end() - 1);
+  for (size_t k = 0; k < tgt.size(); ++k)      // k ascending = elements ascending: the fixed summation order
+    if (tgt[k] >= 0) aidx[pos[tgt[k]]++] = (int)k;
+  c_npairs.upload(cn.data(), cn.size());
+  c_tptr.upload(ctp.data(), ctp.size());
+  c_terms.upload(cte.data(), cte.size());
+  this->aptr.upload(aptr.data(), aptr.size());
+  this->aidx.upload(aidx.data(), aidx.size());
+  elmat.alloc((size_t)E.nel * npm);
+  hip_check(hipMemset(elmat.p, 0, elmat.n * sizeof(double)), "memset elmat");      // slots beyond a class's pair count stay zero
+  view.npm = npm;
+  view.ntm = ntm;
+  view.nnzA = nnzA;
+  view.slot_doubles = nzm + blk * nY;      // vs, ys
+  if ((size_t)(256 / E.tpe) * view.slot_doubles * 8 > 60 * 1024) {
+    view = DevElAsm();
+    return false;
+  }
+  view.c_npairs = c_npairs.p;
+  view.c_tptr = c_tptr.p;
+  view.c_terms = c_terms.p;
+  view.aptr = this->aptr.p;
+  view.aidx = this->aidx.p;
+  // the host copies of the element tables are no longer needed
+  std::vector<int>().swap(EO.h_ecols);
+  std::vector<int>().swap(EO.h_cls);
+  std::vector<unsigned short>().swap(EO.h_tptr);
+  std::vector<unsigned long long>().swap(EO.h_ent);
   return true;
 }
 
@@ -340,7 +481,7 @@ void Amg::mg_level_values(Level& lv, bool mf) {
   }
   // assembled: lower-triangle values from the level's Hessian plan (the reference's recipe evaluated on its fixed pattern,
   // test/test_map_rows_compare.jl:102-123), mirrored into the full symmetric storage the smoother sweeps over
-  launch_spmv(ctx_.stream, lv.T.view, Y_.p, nullptr, lv.avals.p);
+  assemble_values(lv);
   launch_expand_sym(ctx_.stream, m.A.view.nnz, m.amap.p, lv.avals.p, m.A.vals.p, lv.plan.N, m.diagpos.p, m.dinv.p);
 }
 

@@ -219,6 +219,55 @@ __global__ __launch_bounds__(kBlock) void elop_apply_kernel(DevElOp E, int K, in
   }
 }
 
+// Element matrices for the assembly (mg.hpp: DevElAsm).  The element's nonzero values and its Y are staged in LDS; one lane per
+// structurally nonzero pair (i >= j) then sums the pair's products  v[k1] * Y[node, slot] * v[k2]  listed once per structure class
+// (the class-level restriction of the reference's recipe, test/test_map_rows_compare.jl:111-122): no searching, fixed order.
+template <int TPE>
+__global__ __launch_bounds__(kBlock) void elop_assemble_kernel(DevElOp E, DevElAsm A, int nY, const double* __restrict__ Y,
+                                                                double* __restrict__ elmat) {
+  extern __shared__ double lds_el[];
+  constexpr int EPB = kBlock / TPE;
+  const int rpe = E.rows_per_el, nzm = E.nnz_max, nYel = E.block * nY;
+  const int el = threadIdx.x / TPE, ln = threadIdx.x % TPE;
+  double* vs = lds_el + (size_t)el * A.slot_doubles;
+  double* ys = vs + nzm;
+  const int npass = (E.nel + EPB - 1) / EPB;
+  for (int ps = xcd_block(blockIdx.x, gridDim.x); ps < npass; ps += gridDim.x) {
+    const int e = ps * EPB + el;
+    const bool live = e < E.nel;
+    __syncthreads();
+    if (live) {
+      const int k0 = E.rowptr[(size_t)e * rpe], nz = E.rowptr[(size_t)(e + 1) * rpe] - k0;
+      for (int k = ln; k < nz; k += TPE) vs[k] = E.vals[k0 + k];
+      for (int i = ln; i < nYel; i += TPE) ys[i] = Y[(size_t)e * nYel + i];
+    }
+    __syncthreads();
+    if (live) {
+      const int c = E.cls[e], np = A.c_npairs[c];
+      const int* tptr = A.c_tptr + (size_t)c * (A.npm + 1);
+      const unsigned long long* terms = A.c_terms + (size_t)c * A.ntm;
+      for (int s = ln; s < np; s += TPE) {
+        double acc = 0.0;
+        for (int t = tptr[s]; t < tptr[s + 1]; ++t) {
+          const unsigned long long w = terms[t];
+          acc += vs[w & 0xffffu] * ys[(w >> 32) & 0xffffu] * vs[(w >> 16) & 0xffffu];
+        }
+        elmat[(size_t)e * A.npm + s] = acc;
+      }
+    }
+  }
+}
+
+// out[r] = sum_{k in ptr[r] .. ptr[r + 1]} in[idx[k]], fixed order
+__global__ __launch_bounds__(kBlock) void gather_sum_kernel(int n, const int* __restrict__ ptr, const int* __restrict__ idx,
+                                                             const double* __restrict__ in, double* __restrict__ out) {
+  for (long long r = (long long)blockIdx.x * kBlock + threadIdx.x; r < n; r += (long long)gridDim.x * kBlock) {
+    double t = 0.0;
+    for (int k = ptr[r]; k < ptr[r + 1]; ++k) t += in[idx[k]];
+    out[r] = t;
+  }
+}
+
 __device__ inline double mg_epilogue(const MgEpi& E, int i, double t) {
   switch (E.mode) {
     case MG_PLAIN:
@@ -553,6 +602,26 @@ void launch_elop_phase1(hipStream_t st, const DevElOp& E, const BarrierParams& P
 }
 
 }  // namespace
+
+void launch_elop_assemble(hipStream_t st, const DevElOp& E, const DevElAsm& A, BarrierParams P, const double* Y, double* elmat,
+                          double* avals) {
+  if (!E.valid() || !A.valid()) return;
+  const int epb = kBlock / E.tpe;
+  const int npass = (E.nel + epb - 1) / epb;
+  const int grid = std::max(1, std::min(npass, kMaxBlocks * 2));
+  const size_t lds = (size_t)epb * A.slot_doubles * sizeof(double);
+#define MGB_ELASM(T) hipLaunchKernelGGL(elop_assemble_kernel<T>, dim3(grid), dim3(kBlock), lds, st, E, A, P.nY(), Y, elmat)
+  switch (E.tpe) {
+    case 8: MGB_ELASM(8); break;
+    case 16: MGB_ELASM(16); break;
+    case 32: MGB_ELASM(32); break;
+    case 64: MGB_ELASM(64); break;
+    case 128: MGB_ELASM(128); break;
+    default: MGB_ELASM(256); break;
+  }
+#undef MGB_ELASM
+  hipLaunchKernelGGL(gather_sum_kernel, dim3(grid_for(A.nnzA)), dim3(kBlock), 0, st, A.nnzA, A.aptr, A.aidx, elmat, avals);
+}
 
 void launch_elop_apply(hipStream_t st, const DevElOp& E, BarrierParams P, const double* Y, double* elbuf, const MgEpi& epi) {
   if (!E.valid() || E.N == 0) return;

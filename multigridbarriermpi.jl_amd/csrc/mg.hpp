@@ -38,6 +38,25 @@ struct DevElOp {
   bool valid() const { return nel > 0; }
 };
 
+// Element-slab assembly of the Newton matrix (replaces the plan T of amg.hpp where the rows of B come in element
+// blocks): per element the structurally nonzero lower-triangle pairs (i >= j) of its columns -- listed once per structure class
+// -- are formed as  sum_q b_qi' Y_q b_qj  into `elmat` (nel x npm), and every lower-triangle entry of A then sums its element
+// slots in a fixed order (gather form: reproducible).  Reference recipe: test/test_map_rows_compare.jl:102-123,165-170.
+struct DevElAsm {
+  int npm = 0, nnzA = 0, slot_doubles = 0, ntm = 0;
+  const int* c_npairs = nullptr;               // ncls: pair slots of the class
+  // per class and pair slot the products that make up  b_i' Y b_j : offsets c_tptr (ncls x (npm + 1)) into c_terms (ncls x ntm),
+  // one 64-bit record per product: bits 0-15 / 16-31 the two local nonzero indices, 32-47 the Y entry (node * nY + slot)
+  const int* c_tptr = nullptr;
+  const unsigned long long* c_terms = nullptr;
+  const int* aptr = nullptr;                   // nnzA + 1
+  const int* aidx = nullptr;                   // element slots e * npm + s, elements ascending
+  bool valid() const { return npm > 0; }
+};
+// elmat: nel x npm doubles of scratch; avals: the lower-triangle values in pattern order
+void launch_elop_assemble(hipStream_t st, const DevElOp& E, const DevElAsm& A, BarrierParams P, const double* Y, double* elmat,
+                          double* avals);
+
 // What happens to t_i = (A vin)_i in the launch that produces it (one pass over the operator per Chebyshev step / CG product):
 enum MgMode {
   MG_PLAIN = 0,      // out[i] = t

@@ -273,7 +273,9 @@ def test_float32_kernels_match_the_oracle_and_the_double_kernels(M, kind, L, p):
         assert np.abs(H32 - H_o).max() <= 2e-5 * np.abs(H_o).max()
         # the same templates, T = double: the production kernels, bit for bit
         assert np.array_equal(A.f1_template_f64(l, sg, t), A.f1(l, sg, t))
-        assert np.array_equal(A.f2_template_f64(l, sg, t), A.f2(l, sg, t)[1])
+        # f2: the template instantiation goes through the plan T, the production path assembles element by element (round 3):
+        # the same recipe in another summation order
+        assert rel(A.f2_template_f64(l, sg, t), A.f2(l, sg, t)[1]) < 1e-13
         # and float really is float: it differs from the double result, but only at float accuracy
         g64 = A.f1(l, sg, t)
         d = rel(g32.astype(np.float64), g64)
