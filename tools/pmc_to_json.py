@@ -9,7 +9,9 @@ import sys
 CLASSES = {          # rocprofv3 kernel name fragment -> bench.py kernel class
     "front_start_kernel": "chol_front_start", "front_step_kernel": "chol_front_step", "front_step2_kernel": "chol_front_step", "front_single_kernel": "chol_front_single", "front_leaf_kernel": "chol_front_leaf",
     "backward_rect_kernel": "chol_backward_rect", "backward_kernel": "chol_backward",
-    "spmv_kernel<4>": "apply_D", "spmv_kernel<8>": "hessian_assemble", "spmv_kernel<16>": "restrict",
+    "spmv_kernel_t<4,": "apply_D", "spmv_kernel_t<8,": "hessian_assemble_plan", "spmv_kernel_t<16,": "restrict",
+    "elop_assemble_kernel": "hessian_assemble", "gather_sum_kernel": "hessian_assemble_gather",
+    "barrier_f1_kernel_t": "barrier_f1", "barrier_f2_kernel_t": "barrier_f2",
     "barrier_f0_kernel": "barrier_f0_unfused", "trial_f0_kernel": "barrier_f0", "barrier_f1_kernel": "barrier_f1", "barrier_f2_kernel": "barrier_f2",
 }
 

@@ -15,7 +15,7 @@ import sys
 
 def short(name):
     for k in ("front_leaf", "front_single", "front_start", "front_step", "backward_rect", "backward_kernel", "trial_f0", "barrier_f0",
-              "barrier_f1", "barrier_f2", "spmv_kernel", "dot_kernel", "sum_kernel", "final_sum", "waxpby", "copyBuffer", "fillBuffer",
+              "barrier_f1", "barrier_f2", "spmv_kernel", "elop_assemble", "gather_sum", "elop_apply", "dof_gather", "csr_apply", "dot_kernel", "sum_kernel", "final_sum", "waxpby", "copyBuffer", "fillBuffer",
               "front_top"):
         if k in name:
             return k
