@@ -1,6 +1,5 @@
 #include "amg.hpp"
 
-#include <immintrin.h>
 
 #include <chrono>
 #include <cmath>
@@ -13,6 +12,17 @@ namespace mgb {
 
 void hip_check(hipError_t e, const char* what) {
   if (e != hipSuccess) throw HipError(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+
+// spin-wait hint of the host poll loops (portable: the pause / yield instruction where the compiler knows one)
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  std::this_thread::yield();
+#endif
 }
 
 static double now_s() {
@@ -747,7 +757,7 @@ void Amg::wait_signal(const char* what) {
   const volatile unsigned long long* q = h_seq_.p;
   const double t0 = now_s();
   for (unsigned long spins = 0; __atomic_load_n(q, __ATOMIC_ACQUIRE) < seq_expected_; ++spins) {
-    _mm_pause();
+    cpu_relax();
     if ((spins & 0xfffff) == 0xfffff && now_s() - t0 > 10.0) {      // a faulted kernel never signals: surface the HIP error
       hip_check(hipStreamSynchronize(ctx_.stream), what);
       if (__atomic_load_n(q, __ATOMIC_ACQUIRE) < seq_expected_) throw InternalError(std::string("mgb: completion signal lost in ") + what);
@@ -1310,6 +1320,9 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
   //  a launch that threw after its signal was counted must not leave the host counter ahead of the device's
   hip_check(hipStreamSynchronize(ctx_.stream), "sync before solve");
   seq_expected_ = *h_seq_.p;
+  // ... nor its reduction tickets half taken: they are re-armed by the last arriver of a launch only (smaller items)
+  hip_check(hipMemsetAsync(partials_.p, 0, kReductionHeader * sizeof(double), ctx_.stream), "re-arm tickets");
+  if (mg_scratch_.p) hip_check(hipMemsetAsync(mg_scratch_.p, 0, kReductionHeader * sizeof(double), ctx_.stream), "re-arm tickets");
   std::vector<long long> its(L, 0);
   refresh_dz0();
   // the continuation ends at a FIXED t: the first value of the nominal sequence t0 kappa0^k beyond 1 / tol (oracle amgb_core:

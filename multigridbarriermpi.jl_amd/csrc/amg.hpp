@@ -96,7 +96,9 @@ struct PinnedBuf {
     if (p) (void)hipHostFree(p);
     p = nullptr;
     n = count;
-    if (count) hip_check(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault), "hipHostMalloc");
+    // coherent (uncached on the device side) on purpose: the kernels write results and sequence numbers here with system-scope
+    // stores while the host polls -- not left to the runtime's default
+    if (count) hip_check(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocCoherent), "hipHostMalloc");
   }
 };
 
