@@ -856,8 +856,19 @@ double Amg::dev_f1(Level& lv, const double* dz, double t, double* g_out, SolveSt
   timer_.begin(ctx_.stream, KC_RESTRICT, csr_bytes(lv.BT.view, false));
   launch_spmv(ctx_.stream, lv.BT.view, v_.p, nullptr, g_out);
   timer_.end(ctx_.stream);
-  ctx_.allreduce_sum(g_out, lv.plan.N);      // sharded: interface dofs are summed across the row blocks
-  launch_dot(ctx_.stream, lv.plan.N, g_out, g_out, partials_.p, scal_.p + 2, host_scal(scal_.p + 2), nullptr, nullptr, next_signal());
+  if (owner_local(lv)) {
+    // only the top (separator) unknowns are touched by more than one rank's rows: their partial sums and the interior part
+    // of |g|^2 travel (ntop + 1 doubles instead of N); g comes back complete on this rank's own unknowns and on the top
+    const int ntop = lv.gchol.ntop_unknowns();
+    if (gtop_.n < (size_t)ntop + 1) gtop_.alloc((size_t)ntop + 1);
+    launch_gather_top(ctx_.stream, ntop, lv.gchol.top_unknowns(), g_out, gtop_.p);
+    launch_dot_owned(ctx_.stream, lv.plan.N, g_out, g_out, lv.gchol.unknown_kind(), 0, partials_.p, gtop_.p + ntop);
+    ctx_.allreduce_sum(gtop_.p, ntop + 1);
+    launch_scatter_top_norm(ctx_.stream, ntop, lv.gchol.top_unknowns(), gtop_.p, g_out, scal_.p + 2);
+  } else {
+    ctx_.allreduce_sum(g_out, lv.plan.N);      // sharded: interface dofs are summed across the row blocks
+    launch_dot(ctx_.stream, lv.plan.N, g_out, g_out, partials_.p, scal_.p + 2, host_scal(scal_.p + 2), nullptr, nullptr, next_signal());
+  }
   if (ctx_.world > 1)
     hip_check(hipMemcpyAsync(h_scal_.p + 2, scal_.p + 2, sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H gg");
   if (host_solve_)
@@ -1029,9 +1040,14 @@ bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, do
         hip_check(hipEventCreate(&e1), "event");
         hip_check(hipEventRecord(e0, ctx_.stream), "record");
       }
-      lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g.p, lv.nstep.p, tm, /*flag_armed=*/flag_rides && lv.flag_armed);
+      const bool olocal = owner_local(lv);
+      lv.gchol.factor_solve(ctx_.stream, lv.avals.p, lv.g.p, lv.nstep.p, tm, /*flag_armed=*/flag_rides && lv.flag_armed, false, olocal);
       if (time_chain) hip_check(hipEventRecord(e1, ctx_.stream), "record");
-      if (flag_rides) {
+      if (olocal) {
+        // <g, n> summed over the owners (rank 0 counts the replicated top) and the pivot flag: both ride in the trials' collective
+        launch_dot_owned(ctx_.stream, N, lv.g.p, lv.nstep.p, lv.gchol.unknown_kind(), ctx_.rank == 0, partials_.p, scal_.p + 3);
+        launch_flag_to_double(ctx_.stream, lv.gchol.fail_flag(), scal_.p + 10);
+      } else if (flag_rides) {
         launch_dot(ctx_.stream, N, lv.g.p, lv.nstep.p, partials_.p, scal_.p + 3, host_scal(scal_.p + 3), lv.gchol.fail_flag(),
                    h_flag_.p, spec ? HostSignal() : next_signal());
         lv.flag_armed = true;
@@ -1041,14 +1057,19 @@ bool Amg::dev_f2_solve(Level& lv, const double* dz, double t, SolveStats& st, do
       }
       if (spec) {
         enqueue_spec_trials(lv, spec, next_signal());
-        ctx_.allreduce_sum(scal_.p + 4, 2 * spec_count());      // sharded: all speculated trials' partial sums in one collective
+        if (!olocal) ctx_.allreduce_sum(scal_.p + 4, 2 * spec_count());      // sharded: all speculated trials' partial sums in one collective
         st.n_f0 += spec_count();
       }
-      if (ctx_.world > 1)
+      if (olocal) {      // ONE collective: <g, n>, the (up to three) trial pairs, the pivot flag
+        if (!spec) hip_check(hipMemsetAsync(scal_.p + 4, 0, 6 * sizeof(double), ctx_.stream), "zero trial slots");
+        ctx_.allreduce_sum(scal_.p + 3, 8);
+        hip_check(hipMemcpyAsync(h_scal_.p + 3, scal_.p + 3, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx_.stream), "D2H inc + trials + flag");
+      } else if (ctx_.world > 1)
         hip_check(hipMemcpyAsync(h_scal_.p + 3, scal_.p + 3, (spec ? 1 + 2 * spec_count() : 1) * sizeof(double),
                                  hipMemcpyDeviceToHost, ctx_.stream), "D2H inc + trials");
     }
     wait_signal("sync solve");
+    if (owner_local(lv)) h_flag_.p[0] = h_scal_.p[10] != 0.0 ? 1 : 0;
     if (spec)
       for (int q = 0; q < spec_count(); ++q) {
         spec[q].y = h_scal_.p[4 + 2 * q] + t * h_scal_.p[5 + 2 * q];
@@ -1304,6 +1325,11 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
       a->timer_.enable(false);
     }
   } live_guard{this};
+  in_solve_ = true;
+  struct SolveFlag {
+    bool& f;
+    ~SolveFlag() { f = false; }
+  } solve_flag{in_solve_};
   const double t_begin = now_s();
   const double lam_tol = std::sqrt(w_min_) / 2;
   double t = opt.t0, kappa = opt.kappa;

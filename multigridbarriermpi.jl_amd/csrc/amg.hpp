@@ -408,6 +408,12 @@ class Amg {
   void enqueue_f2_assemble(Level& lv, const double* dz, SolveStats& st);
   // sharded + device factorisation whose subtrees follow the row partition: Hessian values are NOT summed over the ranks
   bool values_stay_local(Level& lv);
+  // ... and inside a solve the Newton vectors (gradient, step, iterate) are OWNER-LOCAL too: valid on this rank's own unknowns and
+  // on the replicated top, the only entries its rows touch.  The gradient's collective shrinks to the top entries + one scalar,
+  // the step needs none, dots are summed over the owners.
+  bool owner_local(Level& lv) { return in_solve_ && values_stay_local(lv); }
+  bool in_solve_ = false;
+  DevBuf<double> gtop_;
   struct EventHolder {      // owns the event the host waits on for |g|
     hipEvent_t e = nullptr;
     ~EventHolder() {

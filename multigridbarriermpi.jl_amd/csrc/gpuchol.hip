@@ -1224,6 +1224,12 @@ __global__ __launch_bounds__(256) void xsol_pack_kernel(int n, const int* __rest
     xs[i] = (i == n) ? (*fail ? 1.0 : 0.0) : (own[i] ? x[i] : 0.0);
 }
 
+// owner-local solution: keep x on this rank's own unknowns and on the top, zero elsewhere
+__global__ __launch_bounds__(256) void x_local_kernel(int n, const int* __restrict__ kind, double* __restrict__ x) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    if (kind[i] == 0) x[i] = 0.0;
+}
+
 __global__ __launch_bounds__(256) void xsol_unpack_kernel(int n, const double* __restrict__ xs, double* __restrict__ x, int* fail) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (long long)gridDim.x * blockDim.x) {
     if (i == n) *fail = xs[n] != 0.0 ? 1 : 0;
@@ -1597,6 +1603,17 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
       if (part_.owner[t] == my_rank || (part_.owner[t] < 0 && my_rank == 0))
         for (int k = 0; k < nodes[t].ns; ++k) own[sym.perm_[nodes[t].first + k]] = 1;
     d_own_orig_ = upload(own);
+    std::vector<int> kind(n_, 0), top_unk;
+    for (int t = 0; t < nnodes_; ++t)
+      for (int k = 0; k < nodes[t].ns; ++k) {
+        const int i = sym.perm_[nodes[t].first + k];
+        kind[i] = part_.owner[t] < 0 ? 2 : (part_.owner[t] == my_rank ? 1 : 0);
+        if (part_.owner[t] < 0) top_unk.push_back(i);
+      }
+    std::sort(top_unk.begin(), top_unk.end());
+    d_kind_orig_ = upload(kind);
+    ntop_unk_ = (int)top_unk.size();
+    d_top_unk_ = upload(top_unk);
     vals_local_ = sym.rank_aligned(part_.world);
     if (vals_local_) {
       const std::vector<int> top_idx = sym.top_value_indices(part_);
@@ -1642,7 +1659,7 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
 // (values, rhs, solution) pointer triple into a hipGraph and replayed with ONE host call per Newton step; the
 // event-timed and phase-stamped variants (KernelTimer, MGB_CHOL_PROF) and MGB_CHOL_GRAPH=0 use plain launches.
 void GpuChol::factor_solve(hipStream_t st, double* d_vals, const double* d_b, double* d_x, KernelTimer* tm, bool flag_armed,
-                           bool values_summed) {
+                           bool values_summed, bool x_local) {
   if (n_ == 0) return;
   static const bool use_graph = [] {
     const char* e = std::getenv("MGB_CHOL_GRAPH");
@@ -1652,7 +1669,7 @@ void GpuChol::factor_solve(hipStream_t st, double* d_vals, const double* d_b, do
   // to leave garbage in the flag when another library used the device between replays)
   if (!flag_armed) ck(hipMemsetAsync(d_fail_, 0, sizeof(int), st), "memset flag");
   if (part_.split()) {      // two collectives inside: plain launches, no graph
-    factor_solve_split(st, d_vals, d_b, d_x, tm, values_summed);
+    factor_solve_split(st, d_vals, d_b, d_x, tm, values_summed, x_local && vals_local_ && !values_summed);
     return;
   }
   if (!use_graph || tm || d_prof_) {
@@ -1751,7 +1768,8 @@ void GpuChol::enqueue_chain(hipStream_t st, const double* d_vals, const double* 
   ck(hipGetLastError(), "chain launches");
 }
 
-void GpuChol::factor_solve_split(hipStream_t st, double* d_vals, const double* d_b, double* d_x, KernelTimer* tm, bool values_summed) {
+void GpuChol::factor_solve_split(hipStream_t st, double* d_vals, const double* d_b, double* d_x, KernelTimer* tm, bool values_summed,
+                                 bool x_local) {
   int nprof = 0;
   const bool ride = vals_local_ && !values_summed;
   const int ntop = ride ? ntop_vals_ : 0;
@@ -1770,6 +1788,11 @@ void GpuChol::factor_solve_split(hipStream_t st, double* d_vals, const double* d
   enqueue_backward(st, plan_top_, d_x, tm);
   enqueue_backward(st, plan_, d_x, tm);
   const int grid = std::min(2048, (n_ + 256) / 256);
+  if (x_local) {      // every rank holds what its rows need: its subtree's unknowns and the replicated top
+    hipLaunchKernelGGL(x_local_kernel, dim3(grid), dim3(256), 0, st, n_, d_kind_orig_, d_x);
+    ck(hipGetLastError(), "x_local");
+    return;
+  }
   hipLaunchKernelGGL(xsol_pack_kernel, dim3(grid), dim3(256), 0, st, n_, d_own_orig_, d_x, d_fail_, d_xsol_);
   ck(hipGetLastError(), "xsol pack");
   ctx_->allreduce_sum(d_xsol_, (long long)n_ + 1);                       // x (one contributor per unknown) + pivot flag

@@ -103,8 +103,15 @@ class GpuChol {
   // flag_armed: the caller guarantees the pivot flag is zero (it re-arms it itself behind the chain): no memset launch
   // d_vals is written only when values_local() (top entries <- their sums over the ranks)
   // values_summed: d_vals already holds the sums over the ranks on every rank (a matrix handed in from outside)
+  // x_local (split + values_local only): d_b holds this rank's own-interior entries and the SUMMED entries of the top unknowns
+  // (zeros / anything elsewhere); d_x comes back valid on the same set and zero elsewhere, and the pivot flag stays on the device
+  // unreduced -- no collective for x: the caller folds the flag into its scalar reduction (Amg: owner-local Newton vectors)
   void factor_solve(hipStream_t st, double* d_vals, const double* d_b, double* d_x, KernelTimer* timer = nullptr,
-                    bool flag_armed = false, bool values_summed = false);
+                    bool flag_armed = false, bool values_summed = false, bool x_local = false);
+  // per unknown (original ordering) of a split factorisation: 0 = interior of another rank's subtree, 1 = of this rank's, 2 = top
+  const int* unknown_kind() const { return d_kind_orig_; }
+  const int* top_unknowns() const { return d_top_unk_; }      // original indices of the top (separator) unknowns
+  int ntop_unknowns() const { return ntop_unk_; }
   // the bare launch chain (no flag re-arm, no graph of its own): for callers that capture it into a larger graph together
   // with what follows the solve.  Not for split factorisations (their collectives cannot be captured).
   void enqueue_chain(hipStream_t st, const double* d_vals, const double* d_b, double* d_x);
@@ -122,7 +129,11 @@ class GpuChol {
   void enqueue_forward(hipStream_t st, const std::vector<HeightPlan>& plan, const double* d_vals, const double* d_b, KernelTimer* tm,
                        int& nprof);
   void enqueue_backward(hipStream_t st, const std::vector<HeightPlan>& plan, double* d_x, KernelTimer* tm);
-  void factor_solve_split(hipStream_t st, double* d_vals, const double* d_b, double* d_x, KernelTimer* tm, bool values_summed);
+  void factor_solve_split(hipStream_t st, double* d_vals, const double* d_b, double* d_x, KernelTimer* tm, bool values_summed,
+                          bool x_local);
+  int* d_kind_orig_ = nullptr;
+  int* d_top_unk_ = nullptr;
+  int ntop_unk_ = 0;
   Ctx* ctx_ = nullptr;
   CholPartition part_;
   long long xchg_doubles_ = 0;

@@ -333,6 +333,42 @@ __global__ __launch_bounds__(kBlock) void dot_kernel(int n, const double* __rest
   grid_finish<1>(r, scratch, out_dev, out_host, lds, sig);
 }
 
+__global__ __launch_bounds__(kBlock) void dot_owned_kernel(int n, const double* __restrict__ x, const double* __restrict__ y,
+                                                            const int* __restrict__ kind, int count_top, double* scratch,
+                                                            double* out_dev) {
+  __shared__ double lds[kBlock / 64];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+    const int k = kind[i];
+    if (k == 1 || (k == 2 && count_top)) acc += x[i] * y[i];      // select, never multiply by a mask: the other entries may hold anything
+  }
+  const double r[1] = {block_sum(acc, lds)};
+  grid_finish<1>(r, scratch, out_dev, nullptr, lds);
+}
+
+__global__ __launch_bounds__(kBlock) void gather_top_kernel(int ntop, const int* __restrict__ top, const double* __restrict__ g,
+                                                             double* __restrict__ buf) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < ntop; i += (long long)gridDim.x * kBlock) buf[i] = g[top[i]];
+}
+
+// one workgroup: scatter the summed top entries back and finish |g|^2 in a fixed order
+__global__ __launch_bounds__(kBlock) void scatter_top_norm_kernel(int ntop, const int* __restrict__ top, const double* __restrict__ buf,
+                                                                   double* __restrict__ g, double* out) {
+  __shared__ double lds[kBlock / 64];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < ntop; i += kBlock) {
+    const double v = buf[i];
+    g[top[i]] = v;
+    acc += v * v;
+  }
+  const double tot = block_sum(acc, lds);
+  if (threadIdx.x == 0) out[0] = buf[ntop] + tot;
+}
+
+__global__ void flag_to_double_kernel(const int* flag_dev, double* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = *flag_dev != 0 ? 1.0 : 0.0;
+}
+
 __global__ __launch_bounds__(kBlock) void sum_kernel(int n, const double* __restrict__ x, double* scratch, double* out_dev,
                                                       double* out_host) {
   __shared__ double lds[kBlock / 64];
@@ -444,6 +480,23 @@ void launch_expand_hessian_rows(hipStream_t st, int n, BarrierParams P, const do
 void launch_dot(hipStream_t st, int n, const double* x, const double* y, double* scratch, double* out, double* out_host,
                 int* flag_dev, int* flag_host, HostSignal sig) {
   hipLaunchKernelGGL(dot_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, x, y, scratch, out, out_host, flag_dev, flag_host, sig);
+}
+
+void launch_dot_owned(hipStream_t st, int n, const double* x, const double* y, const int* kind, int count_top, double* scratch,
+                      double* out) {
+  hipLaunchKernelGGL(dot_owned_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, n, x, y, kind, count_top, scratch, out);
+}
+
+void launch_gather_top(hipStream_t st, int ntop, const int* top, const double* g, double* buf) {
+  if (ntop > 0) hipLaunchKernelGGL(gather_top_kernel, dim3(grid_for(ntop)), dim3(kBlock), 0, st, ntop, top, g, buf);
+}
+
+void launch_scatter_top_norm(hipStream_t st, int ntop, const int* top, const double* buf, double* g, double* out) {
+  hipLaunchKernelGGL(scatter_top_norm_kernel, dim3(1), dim3(kBlock), 0, st, ntop, top, buf, g, out);
+}
+
+void launch_flag_to_double(hipStream_t st, const int* flag_dev, double* out) {
+  hipLaunchKernelGGL(flag_to_double_kernel, dim3(1), dim3(64), 0, st, flag_dev, out);
 }
 
 void launch_sum(hipStream_t st, int n, const double* x, double* scratch, double* out, double* out_host) {

@@ -144,6 +144,17 @@ void launch_expand_hessian_rows(hipStream_t st, int n, BarrierParams P, const do
 // stream travels to pinned host memory with the dot product and is re-armed)
 void launch_dot(hipStream_t st, int n, const double* x, const double* y, double* scratch, double* out, double* out_host = nullptr,
                 int* flag_dev = nullptr, int* flag_host = nullptr, HostSignal sig = HostSignal());
+// Owner-local vectors of a sharded job: `kind[i]` = 0 another rank's interior unknown, 1 this rank's, 2 top
+// (replicated).  out[0] = sum over the unknowns this rank answers for -- its own, and the top ones iff count_top -- of x_i y_i;
+// summed over the ranks that is the full dot product.
+void launch_dot_owned(hipStream_t st, int n, const double* x, const double* y, const int* kind, int count_top, double* scratch,
+                      double* out);
+// buf[i] = g[top[i]], i < ntop   (this rank's partial sums at the top unknowns, to be summed over the ranks)
+void launch_gather_top(hipStream_t st, int ntop, const int* top, const double* g, double* buf);
+// g[top[i]] = buf[i];  out[0] = buf[ntop] + sum_i buf[i]^2   (|g|^2 from the summed interior part and the summed top entries);
+// flag_dev (nullable): out[1] = (*flag_dev != 0)
+void launch_scatter_top_norm(hipStream_t st, int ntop, const int* top, const double* buf, double* g, double* out);
+void launch_flag_to_double(hipStream_t st, const int* flag_dev, double* out);
 // out[0] = sum x_i ; scratch of kReductionHeader + f0_blocks(n) doubles
 void launch_sum(hipStream_t st, int n, const double* x, double* scratch, double* out, double* out_host = nullptr);
 // flag[0] = 1 if all finite else 0
