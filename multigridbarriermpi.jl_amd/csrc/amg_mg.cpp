@@ -878,13 +878,15 @@ Amg::MgKernelTimes Amg::time_mg_kernels(int l, int reps, int nrot) {
   kt.bytes[0] = hv;
   kt.bytes[1] = hv + 5.0 * N * 8;      // + x, r read and written, dinv read, d_new written (out counted in hv)
   kt.bytes[2] = (double)m.A.view.nnz * 12 + (N + 1.0) * 4 + 2.0 * N * 8;
-  // "2 x apply_D-class passes + 3 vectors" on CSR operands
-  const double csrB = nnzB * 12 + ((double)lv.B.view.rows + 1) * 4, csrBT = nnzB * 12 + (N + 1.0) * 4;
-  kt.alg[0] = csrB + csrBT + (double)n_ * nY * 8 + 2.0 * N * 8;
-  kt.alg[1] = kt.alg[0] + 3.0 * N * 8;
+  // SURVEY.md section 8(d), literally: a sweep on the matrix-free H = "2 x apply_D-class passes + 3 vectors", an apply_D-class pass =
+  // nnz * 12 + (rows + 1) * 4 + cols * 8 + rows * 16 on the CSR operand (what KC_APPLY is priced at everywhere else)
+  const double pass = nnzB * 12 + ((double)lv.B.view.rows + 1) * 4 + N * 8.0 + (double)lv.B.view.rows * 16;
+  kt.alg[0] = 2.0 * pass;
+  kt.alg[1] = 2.0 * pass + 3.0 * N * 8;
   kt.alg[2] = kt.bytes[2];
   // the unfused sequence: Dz = B v (write n K), u = Y Dz (read n K + Y, write n K), g = B' u (read n K)
-  kt.bytes[5] = kt.alg[0] + 4.0 * n_ * P_.K * 8;
+  // the unfused sequence with the tightest CSR accounting: B and B' once each, Y, the two vectors, Dz and u written and read
+  kt.bytes[5] = nnzB * 24 + ((double)lv.B.view.rows + N + 2) * 4 + (double)n_ * nY * 8 + 2.0 * N * 8 + 4.0 * n_ * P_.K * 8;
   if (has_coarse) {
     const DevCsr& Pv = lc->mg->P.view;
     kt.bytes[3] = kt.alg[3] = (double)Pv.nnz * 12 + (Pv.rows + 1.0) * 4 + Pv.cols * 8.0 + Pv.rows * 16.0;
