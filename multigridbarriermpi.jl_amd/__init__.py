@@ -1170,9 +1170,109 @@ def _phase1_slack(geometry, M: "AMG", p, z0, c, tol, schedule, solver):
     return np.ascontiguousarray(z1[:, :S]), SOL
 
 
+def _amgb_float32(geometry, M: "AMG", z0, tol, t, kappa, maxit, verbose):
+    """Float32 main phase (the reference runs T = Float32 on its Metal backend, tolerance 1e-4: test/test_utils.jl:67-88,118-119;
+    SURVEY.md section 8 f3).  The Newton loop of oracle amgb_core / newton / line search, driven from the host over the FLOAT
+    instantiation of the device kernels -- objective, gradient and Hessian values through mgb_amg_f0_f32 / f1_f32 / f2_f32 -- with
+    the Newton system solved by the double device Cholesky on the float-assembled values (there is no Float32 factorisation:
+    fp64 runs at the fp32 vector rate on MI355X).  The iterate lives in double between centerings; s, Dz, the barrier terms, the
+    gradient and the Hessian values are float.  Host-driven on purpose: the float path is for the small meshes the reference
+    runs in Float32, not a hot path."""
+    import time as _time
+    l = M.L - 1
+    R = sp.block_diag([geometry.subspaces[sv[1]][l].host for sv in M.state_variables], format="csr")
+    N = R.shape[1]
+    z = np.asarray(z0, dtype=np.float64).reshape(-1, order="F").copy()
+    kappa0, t_begin = kappa, _time.time()
+    t_stop = t
+    while t_stop <= 1.0 / tol:
+        t_stop *= kappa0
+    max_newton, steps = 48, [0]
+
+    def centre(zc, tc):
+        M.set_z(zc)
+        s = np.zeros(N, dtype=np.float32)
+        y = M.f0_f32(l, s, tc)
+        if not math.isfinite(y):
+            return None
+        g = M.f1_f32(l, s, tc).astype(np.float64)
+        ymin, gmin = y, float(np.linalg.norm(g))
+        for _ in range(max_newton):
+            steps[0] += 1
+            try:
+                n = M.solve_linear(l, M.f2_f32(l, s, tc).astype(np.float64), g)
+            except MGBError:
+                return None
+            inc = float(g @ n)
+            if not math.isfinite(inc):
+                return None
+            if inc <= 0:
+                return zc + R @ s.astype(np.float64)
+            step, accepted = 1.0, False
+            while step >= 1e-8:                               # backtracking: finite (amgb_all_isfinite, src:121) + Armijo
+                st = (s.astype(np.float64) - step * n).astype(np.float32)
+                yt = M.f0_f32(l, st, tc)
+                if math.isfinite(yt) and yt <= y - 0.1 * step * inc:
+                    gt = M.f1_f32(l, st, tc).astype(np.float64)
+                    if np.all(np.isfinite(gt)):
+                        accepted = True
+                        break
+                step *= 0.5
+            if not accepted:
+                yt, gt, st = y, g, s
+            gn = float(np.linalg.norm(gt))
+            done = yt >= ymin and gn >= 0.1 * gmin            # stagnation in float precision (oracle stopping_exact)
+            s, y, g = st, yt, gt
+            ymin, gmin = min(ymin, y), min(gmin, gn)
+            if done:
+                return zc + R @ s.astype(np.float64)
+        return None
+
+    def c_dot(zc):
+        M.set_z(zc)
+        return float(M.f0(l, np.zeros(N), 0.0, parts=True)[1][1])
+
+    its, ts, cd = [], [], []
+    zz = None
+    for _ in range(8):                                        # INITIAL_CENTERING_ATTEMPTS
+        zz = centre(z, t)
+        if zz is not None:
+            break
+    if zz is None:
+        raise MGBError(-3, "amgb (Float32): initial centering failed")
+    z = zz
+    its.append(steps[0]); ts.append(t); cd.append(c_dot(z))
+    k = 1
+    while t < t_stop and kappa > 1 and k < maxit:
+        k += 1
+        before = steps[0]
+        while kappa > 1:
+            t1 = min(kappa * t, t_stop)
+            b1 = steps[0]
+            zz = centre(z, t1)
+            if zz is not None:
+                if steps[0] - b1 <= max_newton * 0.25:
+                    kappa = min(kappa0, kappa * kappa)
+                z, t = zz, t1
+                break
+            kappa = math.sqrt(kappa)
+            if kappa < 1 + 1e-3:
+                kappa = 1.0
+        its.append(steps[0] - before); ts.append(t); cd.append(c_dot(z))
+        if verbose:
+            print("[mgb f32] t=%.4g kappa=%.3g its=%d" % (t, kappa, its[-1]))
+    if t < t_stop:
+        raise MGBError(-3, "amgb (Float32): convergence failure (kappa collapsed)")
+    itm = np.zeros((M.L, len(its)), dtype=np.int64)
+    itm[l] = its
+    M.set_z(z)
+    return z.astype(np.float32).astype(np.float64), dict(t_elapsed=_time.time() - t_begin, ts=np.array(ts), its=itm,
+                                                         c_dot_Dz=np.array(cd), T="float32")
+
+
 def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=None, g=None, tol=None, t=0.1,
          maxit=10000, kappa=10.0, verbose=False, logfile=None, schedule="fine", solver="gpu", cones=None, stop_rule="fixed",
-         centering="exact", **rest) -> AMGBSOL:
+         centering="exact", T=np.float64, **rest) -> AMGBSOL:
     """MultiGridBarrier.amgb on an MPI geometry (called at src:599,666).  kwargs as documented in
     docs/src/guide.md:148-152; unknown kwargs (e.g. `L`, forwarded by fem*d_mpi_solve, src:663-666)
     are ignored like Julia's `kwargs...` fan-out.  `cones` (upstream kwarg `Q`: the convex set) selects the barrier terms,
@@ -1219,6 +1319,15 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
                 raise MGBError(-3, "amgb: feasibility phase failed")
             SOL_feasibility = dict(shift=sigma, its=np.zeros((M.L, 0), dtype=np.int64), ts=np.zeros(0),
                                    c_dot_Dz=np.zeros(0), t_elapsed=0.0)
+    if np.dtype(T) == np.float32:                             # the reference's Float32 configurations (test/test_utils.jl:67-88)
+        if SOL_feasibility is not None and "shift" not in SOL_feasibility:
+            raise NotImplementedError("amgb: Float32 covers the closed-form feasibility shift only")
+        M.prepare()
+        tol32 = float(np.sqrt(np.finfo(np.float32).eps)) if tol is None else float(tol)
+        z, SOL = _amgb_float32(geometry, M, z0, tol32, t, kappa, maxit, verbose)
+        return AMGBSOL(HPCMatrix(z.reshape(z0.shape, order="F"), geometry.x.backend), SOL_feasibility, SOL, [], geometry)
+    if np.dtype(T) != np.float64:
+        raise ValueError("T must be float64 or float32")
     M.set_solver(solver)
     if rest.get("pcg"):
         M.set_pcg(**rest["pcg"])      # parameters of solver="pcg", see AMG.set_pcg
