@@ -150,6 +150,11 @@ int mgb_amg_create_terms(mgb_ctx ctx, mgb_geo g, int S, const char* const* state
  * p_nodes[q] = p(x_q) >= 1 at the n (global) nodes; the barrier kernels then use a = 2 / p(x_q) and mu(p(x_q)) per node.
  * Call after mgb_amg_create*, before the first evaluation. */
 int mgb_amg_set_exponents(mgb_amg a, int term, const double* p_nodes);
+/* upstream convex_piecewise (a convex set that varies in space: at x the intersection of the pieces selected there;
+ * [UPSTREAM-UNVERIFIED] semantics): mask[q * nterms + c] != 0 iff barrier term c is active at node q (n
+ * global nodes x the terms of mgb_amg_create_terms); an inactive term contributes nothing at that node.  Every node must keep at
+ * least one term.  Call after mgb_amg_create*, before the first evaluation; the start must be strictly feasible. */
+int mgb_amg_set_term_mask(mgb_amg a, const unsigned char* mask);
 int mgb_amg_destroy(mgb_amg a);
 int mgb_amg_dims(mgb_amg a, int* n, int* S, int* K, int* L, int* nY);   /* n = LOCAL rows on a sharded context */
 int mgb_amg_local_rows(mgb_amg a, int* n_global, int* row0, int* n_local);

@@ -802,7 +802,7 @@ class AMG:
     """AMG hierarchy + barrier problem resident in HBM (upstream `amg` + `barrier`)."""
 
     def __init__(self, geometry: Geometry, state_variables=DEFAULT_STATE, D=None, p: float = 1.0, idx=None,
-                 cones=None):
+                 cones=None, select=None):
         """`cones` = the terms of the barrier (an intersection of up to three convex sets, upstream `intersect`):
         (idx, p) | (idx, p, idx_s2) -- the power cone s >= |q|^p on the D rows idx = (q_1..q_d, s) (convex_Euclidian_power);
         ("linear", idx, coef, off)  -- the half space sum_i coef[i] * Dz[:, idx[i]] + off > 0 (convex_linear with one constant
@@ -848,6 +848,11 @@ class AMG:
         self.n, self.row0, self.n_local = ng.value, r0.value, nl.value
         for ti, pn in node_p.items():
             call("mgb_amg_set_exponents", h, int(ti), dptr(pn))
+        if select is not None:      # upstream convex_piecewise: term c is active at x iff select(x)[c]
+            mask = np.ascontiguousarray([[1 if b else 0 for b in select(xi)] for xi in geometry.x.to_numpy()], dtype=np.uint8)
+            if mask.shape != (self.n, len(cones)):
+                raise ValueError("select(x) must give one flag per barrier term")
+            call("mgb_amg_set_term_mask", h, mask.ctypes.data_as(C.POINTER(C.c_ubyte)))
 
     def prepare(self, l=-1):
         """Build the level(s) and the factorisation structures now (default: every level the schedule visits), so
@@ -1282,7 +1287,7 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
     dim = geometry.discretization["dim"]
     f = DEFAULT_F[dim] if f is None else f
     g = DEFAULT_G[dim] if g is None else g
-    M = AMG(geometry, state_variables, D, p, cones=cones)
+    M = AMG(geometry, state_variables, D, p, cones=cones, select=rest.get("select"))
     x = geometry.x.to_numpy()
     z0 = _rows(g, x)        # g_grid (n, S)
     c = _rows(f, x)         # f_grid (n, K)
@@ -1291,6 +1296,8 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
     Nf = M.level_size(M.L - 1)[0]
     y0 = M.f0(M.L - 1, np.zeros(Nf), 0.0)
     SOL_feasibility = None
+    if not math.isfinite(y0) and rest.get("select") is not None:
+        raise MGBError(-3, "amgb: a piecewise set (select=) needs a strictly feasible start")
     if not math.isfinite(y0):
         # Feasibility phase (SOL_feasibility, src:428-455).  For the power-cone family it has a closed form:
         # the slack row is `id` of a :full state variable (that space contains the constants), so a constant

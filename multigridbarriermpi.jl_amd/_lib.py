@@ -80,6 +80,7 @@ PROTOTYPES = {
     "mgb_amg_create_terms": [H, H, C.c_int, c_str_arr, C.c_int, c_str_arr, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p,
                              c_dbl_p, c_dbl_p, c_dbl_p, C.POINTER(H)],
     "mgb_amg_set_exponents": [H, C.c_int, c_dbl_p],
+    "mgb_amg_set_term_mask": [H, C.POINTER(C.c_ubyte)],
     "mgb_amg_destroy": [H],
     "mgb_amg_dims": [H, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p],
     "mgb_amg_local_rows": [H, c_int_p, c_int_p, c_int_p],

@@ -657,6 +657,21 @@ void Amg::set_exponents(int term, const double* p_nodes) {
   P_.mu_node = mu_node_.p;
 }
 
+void Amg::set_term_mask(const unsigned char* mask) {
+  const int nc = P_.ncones;
+  std::vector<unsigned char> m((size_t)n_ * nc);
+  for (int q = 0; q < n_; ++q) {
+    bool any = false;
+    for (int c = 0; c < nc; ++c) {
+      m[(size_t)q * nc + c] = mask[(size_t)(r0_ + q) * nc + c] ? 1 : 0;
+      any = any || m[(size_t)q * nc + c];
+    }
+    if (!any) throw ArgError("set_term_mask: every node must keep at least one term");
+  }
+  term_mask_.upload(m.data(), m.size());
+  P_.term_mask = term_mask_.p;
+}
+
 // c, z arrive / leave in the GLOBAL layout on every rank; a sharded Amg keeps its own rows
 void Amg::set_c(const double* c_host) { c_.upload(c_host + (size_t)r0_ * P_.K, (size_t)n_ * P_.K); }
 

@@ -307,6 +307,8 @@ class Amg {
   // x-dependent exponent of power-cone term `term` (upstream convex_Euclidian_power with a function p(x)):
   // p_nodes = p at the n_global nodes (>= 1); the barrier kernels then read a = 2 / p and mu(p) per node
   void set_exponents(int term, const double* p_nodes_global);
+  // upstream convex_piecewise: mask[q * nterms + c] != 0 iff term c is active at (global) node q; every node keeps >= 1 term
+  void set_term_mask(const unsigned char* mask_global);
   // solver = pcg for prepare() and the fine-grained entry points between solves (solve() takes it from its options)
   void set_pcg(bool on) { pcg_ = on; }
 
@@ -506,6 +508,7 @@ class Amg {
   bool slack_negative();
   DevBuf<float> w32_, c32_, Dz0_32_, Dz32_, v32_, Y32_;      // Float32 shadows of the row data
   DevBuf<double> rowF_, rowC_, a_node_, mu_node_;
+  DevBuf<unsigned char> term_mask_;
   void ensure_f32(Level& lv);
   BarrierParams P_;
   AmgSpec spec_;

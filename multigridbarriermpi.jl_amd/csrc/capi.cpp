@@ -740,6 +740,12 @@ int mgb_amg_set_exponents(mgb_amg a, int term, const double* p_nodes) {
     a->amg->set_exponents(term, p_nodes);
   });
 }
+int mgb_amg_set_term_mask(mgb_amg a, const unsigned char* mask) {
+  return guard([&] {
+    need(a && mask, "set_term_mask: null argument");
+    a->amg->set_term_mask(mask);
+  });
+}
 int mgb_amg_set_early_stop(mgb_amg a, int col) {
   return guard([&] {
     need(a && col >= -1, "set_early_stop: bad arguments");

@@ -108,6 +108,10 @@ __global__ __launch_bounds__(kBlock) void barrier_f0_kernel(int n, BarrierParams
     const double wq = w[q];
     double F = 0.0;
     for (int ci = 0; ci < P.ncones; ++ci) {
+      if (!P.active(ci, q)) {      // inactive piece: no constraint at this node
+        if (phi_out) phi_out[q * P.ncones + ci] = INFINITY;
+        continue;
+      }
       const ConeAM<double> am = cone_am<double>(P, ci, q);
       Cone k = load_cone<double>(P.cone[ci], dz, am.a);
       if (phi_ref && !(k.phi >= frac * phi_ref[q * P.ncones + ci])) k.ok = false;
@@ -212,6 +216,10 @@ __global__ __launch_bounds__(kBlock) void trial_f0_kernel(int n, int N, BarrierP
       double* phi_out = T.phi_out[pa];
       double F = 0.0;
       for (int ci2 = 0; ci2 < P.ncones; ++ci2) {
+        if (!P.active(ci2, q)) {
+          if (phi_out) phi_out[q * P.ncones + ci2] = INFINITY;
+          continue;
+        }
         const ConeAM<double> am = cone_am<double>(P, ci2, q);
         Cone k = load_cone<double>(P.cone[ci2], dz, am.a);
         if (phi_ref && !(k.phi >= frac * phi_ref[q * P.ncones + ci2])) k.ok = false;
@@ -266,6 +274,7 @@ __global__ __launch_bounds__(kBlock) void barrier_rows_F_kernel(int n, BarrierPa
     const double* dz = Dz + q * P.K;
     double F = 0.0;
     for (int ci = 0; ci < P.ncones; ++ci) {
+      if (!P.active(ci, q)) continue;
       const ConeAM<double> am = cone_am<double>(P, ci, q);
       Cone k = load_cone<double>(P.cone[ci], dz, am.a);
       F += k.ok ? (-log(k.phi) - am.mu * log(k.s)) : INFINITY;

@@ -60,6 +60,10 @@ struct BarrierParams {
   // and term, a = 2 / p(x_q) and mu(p(x_q)) in device arrays of n x ncones doubles; null = the terms' own constants
   const double* a_node = nullptr;
   const double* mu_node = nullptr;
+  // upstream convex_piecewise (a set that varies in space: at x the intersection of the pieces selected there): per node and
+  // term one byte, 0 = the term is inactive at that node (no constraint, no barrier); null = every term everywhere
+  const unsigned char* term_mask = nullptr;
+  __host__ __device__ bool active(int ci, long long q) const { return !term_mask || term_mask[q * ncones + ci]; }
   __host__ __device__ int nY() const {
     int s = 0;
     for (int c = 0; c < ncones; ++c) s += cone[c].nY();

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(kBlock) void barrier_f0_rows_kernel_t(int n, Barrie
     const T* dz = Dz + q * P.K;
     T F = T(0);
     for (int ci = 0; ci < P.ncones; ++ci) {
+      if (!P.active(ci, q)) continue;
       const ConeAM<T> am = cone_am<T>(P, ci, q);
       const ConeT<T> k = load_cone<T>(P.cone[ci], dz, am.a);
       F += k.ok ? (-log(k.phi) - am.mu * log(k.s)) : T(INFINITY);
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(kBlock) void barrier_f1_kernel_t(int n, BarrierPara
     for (int j = 0; j < kMaxK; ++j) vr[j] = (j < P.K) ? wq * (t * cq[j]) : T(0);
     for (int ci = 0; ci < P.ncones; ++ci) {
       const ConeSpec& S = P.cone[ci];
+      if (!P.active(ci, q)) continue;
       const ConeAM<T> am = cone_am<T>(P, ci, q);
       const ConeT<T> k = load_cone<T>(S, dz, am.a);
       if (S.kind == 1) {
@@ -197,6 +199,11 @@ __global__ __launch_bounds__(kBlock) void barrier_f2_kernel_t(int n, BarrierPara
     int slot = 0;
     for (int ci = 0; ci < P.ncones; ++ci) {
       const ConeSpec& S = P.cone[ci];
+      if (!P.active(ci, q)) {      // inactive piece: its slots are zeros
+        const int ns = S.nY();
+        for (int i = 0; i < ns; ++i) yq[slot++] = T(0);
+        continue;
+      }
       const ConeAM<T> am = cone_am<T>(P, ci, q);
       const ConeT<T> k = load_cone<T>(S, dz, am.a);
       if (S.kind == 1) {

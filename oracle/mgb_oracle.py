@@ -567,6 +567,39 @@ class ConeIntersection:
         return sum(Q.F2(x, Y) for Q in self.cones)
 
 
+@dataclass
+class ConvexPiecewise:
+    """upstream `convex_piecewise` [UPSTREAM-UNVERIFIED recollection: a convex set that varies in space -- at x the intersection of
+    the pieces Q[i] with select(x)[i] true]: the barrier at node q is the sum of the barriers of the pieces active there; an
+    inactive piece constrains nothing at that node (distance +inf).  `mask`: n x len(cones) booleans (select evaluated at the
+    nodes)."""
+    cones: Sequence[PowerConeBarrier]
+    mask: np.ndarray
+
+    def phi(self, Y):
+        return np.stack([np.where(self.mask[:, i], Q.phi(Y), np.inf) for i, Q in enumerate(self.cones)], axis=1)
+
+    def F(self, x, Y):
+        with np.errstate(all="ignore"):
+            return sum(np.where(self.mask[:, i], Q.F(x, Y), 0.0) for i, Q in enumerate(self.cones))
+
+    def F1(self, x, Y):
+        with np.errstate(all="ignore"):
+            return sum(np.where(self.mask[:, i, None], Q.F1(x, Y), 0.0) for i, Q in enumerate(self.cones))
+
+    def F2(self, x, Y):
+        with np.errstate(all="ignore"):
+            return sum(np.where(self.mask[:, i, None, None], Q.F2(x, Y), 0.0) for i, Q in enumerate(self.cones))
+
+
+def convex_piecewise(cones, select, x) -> ConvexPiecewise:
+    """select(x_q) -> one boolean per piece; evaluated at the nodes x (n x dim)."""
+    mask = np.array([[bool(b) for b in select(xi)] for xi in x], dtype=bool)
+    if mask.shape != (x.shape[0], len(cones)) or not mask.any(axis=1).all():
+        raise ValueError("convex_piecewise: select(x) must give one flag per piece and keep at least one piece at every node")
+    return ConvexPiecewise(list(cones), mask)
+
+
 class Barrier:
     """upstream `barrier(F)` -> (f0, f1, f2); algebra pinned by
     test/test_apply_d.jl:44 (apply_D), test/test_column_extract.jl:50-80 (f1 pieces) and
@@ -864,7 +897,7 @@ class AMGBSOL:
 
 def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=None, g=None,
          tol=None, t=0.1, maxit=10000, kappa=10.0, verbose=False, logfile=None, keep_log=False,
-         schedule=None, extra=(), cone_idx=None, stop_rule=None) -> AMGBSOL:
+         schedule=None, extra=(), cone_idx=None, stop_rule=None, select=None) -> AMGBSOL:
     """`extra`: further convex sets intersected with the p-Laplace power cone (upstream `intersect`), e.g. LinearBarrier;
     `cone_idx`: the rows (q.., s) of D the power cone acts on (default: the last dim + 1 rows)."""
     dim = geometry.discretization["dim"]
@@ -881,11 +914,16 @@ def amgb(geometry: Geometry, p=1.0, state_variables=DEFAULT_STATE, D=None, f=Non
     Q = convex_Euclidian_power(idx=list(cone_idx) if cone_idx is not None else
                                (list(range(1, dim + 2)) if nD == dim + 2 else list(range(nD - dim - 1, nD))), p=p)
     B = Barrier(ConeIntersection([Q, *extra]) if extra else Q)
+    if select is not None:                       # convex_piecewise: the pieces (Q, *extra), active where select(x) says
+        B = Barrier(convex_piecewise([Q, *extra], select, x))
     zvec = z0.reshape(-1, order="F")
     Dz = B.apply_D(M.D, zvec)
     log = [] if keep_log else None
     SOL_feas = None
-    if extra and not np.all(np.isfinite(B.Q.F(x, Dz))):
+    if select is not None:
+        if not np.all(np.isfinite(B.Q.F(x, Dz))):
+            raise RuntimeError("amgb: a piecewise set needs a strictly feasible start")
+    elif extra and not np.all(np.isfinite(B.Q.F(x, Dz))):
         zvec, SOL_feas = amgb_phase1_slack(geometry, state_variables, M.Dspec, Q, extra, zvec, Dz, tol, schedule, c=c)
     elif not np.all(np.isfinite(Q.F(x, Dz))):
         zvec, SOL_feas = amgb_phase1(geometry, state_variables, M.Dspec, Q, zvec, Dz, tol, schedule)

@@ -892,3 +892,50 @@ def test_float32_solve_at_the_reference_float32_tolerance(M, kind, L, p):
     assert sol.SOL_main["T"] == "float32" and np.array_equal(z, z.astype(np.float32).astype(np.float64))
     assert sol.SOL_main["ts"][-1] == 1e4 and rel(z, zo) < 1e-4
     print("%s L=%d p=%g float32: newton %d, rel l2 vs the double oracle at tol32 %.2e" % (kind, L, p, int(sol.SOL_main["its"].sum()), rel(z, zo)))
+
+
+@pytest.mark.parametrize("kind,L,p,psi", [("fem2d", 3, 1.5, 0.1), ("fem2d", 4, 2.0, 0.2), ("fem1d", 5, 1.5, 0.1)])
+def test_piecewise_set_matches_oracle(M, kind, L, p, psi):
+    """upstream `convex_piecewise` -- a convex set that varies in space ([UPSTREAM-UNVERIFIED] semantics: at x the
+    intersection of the pieces select(x) keeps).  Here the p-Laplace cone everywhere and the obstacle u > psi only on the half
+    x_1 > 0 (mgb_amg_set_term_mask; oracle ConvexPiecewise): kernel level at 1e-12 / 1e-11, the solve at 1e-10; the obstacle is
+    active where it applies and violated where it does not."""
+    dim = 1 if kind == "fem1d" else 2
+    gm = getattr(M, kind + "_mpi")(L)
+    go = getattr(O, kind)(L)
+    cone = (list(range(1, dim + 2)), p)
+    lin = ("linear", [0], [1.0], -psi)
+    select = lambda x: (True, x[0] > 0.0)
+    A = M.AMG(gm, p=p, cones=[cone, lin], select=select)
+    Mo = O.amg(go)
+    z0 = O.map_rows(lambda xi: OBST_G[dim](xi), Mo.x).reshape(-1, order="F")
+    c = O.map_rows(lambda xi: OBST_F[dim](xi), Mo.x)
+    A.set_c(c)
+    A.set_z(z0)
+    Bo = O.Barrier(O.convex_piecewise([O.convex_Euclidian_power(list(range(1, dim + 2)), p), O.LinearBarrier([0], [1.0], -psi)],
+                                      select, Mo.x.reshape(Mo.x.shape[0], -1)))
+    l = L - 1
+    Ro = Mo.R[l]
+    Rg = sp.block_diag([gm.subspaces["dirichlet"][l].host, gm.subspaces["full"][l].host], format="csr")
+    pi = _match_columns(Ro, Rg)
+    N = Ro.shape[1]
+    rng = np.random.default_rng(3)
+    so = 2e-3 * rng.standard_normal(N)
+    sg = np.zeros(N)
+    sg[pi] = so
+    t = 2.5
+    y_o = Bo.f0(so, Mo.x, Mo.w, t * c, Ro, Mo.D, z0)
+    assert np.isfinite(y_o) and abs(A.f0(l, sg, t) - y_o) <= KTOL * abs(y_o)
+    assert rel(A.f1(l, sg, t)[pi], Bo.f1(so, Mo.x, Mo.w, t * c, Ro, Mo.D, z0)) < 1e-11
+    H_o = Bo.f2(so, Mo.x, Mo.w, t * c, Ro, Mo.D, z0).toarray()
+    H_g = A.f2(l, sg, t)[0].toarray()[np.ix_(pi, pi)]
+    assert np.abs(H_g - H_o).max() <= 1e-11 * np.abs(H_o).max()
+    sol = M.amgb(gm, p=p, f=OBST_F[dim], g=OBST_G[dim], cones=[cone, lin], select=select)
+    ref = O.amgb(go, p=p, f=OBST_F[dim], g=OBST_G[dim], extra=[O.LinearBarrier([0], [1.0], -psi)], select=select)
+    z = M.mpi_to_native(sol).z
+    assert rel(z, ref.z) < ZTOL
+    x1 = Mo.x.reshape(Mo.x.shape[0], -1)[:, 0]
+    on, off = z[x1 > 0, 0], z[x1 < 0, 0]
+    assert on.min() > psi and on.min() - psi < 1e-3 and off.min() < psi       # active where selected, ignored elsewhere
+    with pytest.raises(M._lib.MGBError):
+        M.AMG(gm, p=p, cones=[cone, lin], select=lambda x: (False, False))

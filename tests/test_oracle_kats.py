@@ -315,3 +315,17 @@ def test_per_node_exponents_reduce_to_the_scalar_case():
     c = O.amgb(g, p=lambda x: 1.5 + 0.4 * x[0])
     assert np.all(np.isfinite(c.z)) and np.abs(c.z - a.z).max() > 1e-3
     assert np.array_equal(O.barrier_mu(np.array([1.0, 2.0, 3.0])), np.array([1.0, 0.0, 2.0]))
+
+
+def test_piecewise_set_reduces_to_the_intersection_when_everything_is_selected():
+    """oracle ConvexPiecewise (upstream convex_piecewise, [UPSTREAM-UNVERIFIED]): with every piece selected everywhere it is the
+    plain intersection, bit for bit; deselecting the obstacle on one half lets u drop below it there."""
+    g = O.fem2d(3)
+    f = lambda x: np.array([5.0, 0.0, 0.0, 1.0])
+    gg = lambda x: np.array([0.3 + 0.5 * (x[0] ** 2 + x[1] ** 2), 100.0])
+    ob = O.LinearBarrier([0], [1.0], -0.1)
+    a = O.amgb(g, p=1.5, f=f, g=gg, extra=[ob])
+    b = O.amgb(g, p=1.5, f=f, g=gg, extra=[ob], select=lambda x: (True, True))
+    assert np.array_equal(a.z, b.z)
+    c = O.amgb(g, p=1.5, f=f, g=gg, extra=[ob], select=lambda x: (True, x[0] > 0))
+    assert c.z[g.x[:, 0] < 0, 0].min() < 0.1 < c.z[g.x[:, 0] > 0, 0].min()
