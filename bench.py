@@ -51,7 +51,7 @@ def cpu_baseline(L, p, budget_s):
     return dict(value=n * steps.value / sec.value, unit="DoF/s per Newton step", cores=int(threads.value), kind="port",
                 sample="C++ / OpenMP restatement of the same Newton path (oracle/cpu/mgb_cpu_newton.cpp: t-continuation, finest-level "
                        "Newton, line search, barrier f0 / f1 / f2, threaded Hessian plan + host multifrontal Cholesky of the product) "
-                       "on %d host threads: the first %d Newton steps of the same solve (t = 0.1 ... %.3g, stopped after the "
+                       "on %d OpenMP threads (the multifrontal Cholesky inside uses the product's own pool of at most 16): the first %d Newton steps of the same solve (t = 0.1 ... %.3g, stopped after the "
                        "centering that passed the budget) on fem2d L=%d p=%g, %.1f s of host time"
                        % (threads.value, steps.value, t_reached.value, L, p, sec.value))
 
