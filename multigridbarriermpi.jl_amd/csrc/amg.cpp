@@ -753,6 +753,11 @@ void Amg::sync_collect(const char* what) {
   if (live_) timer_.collect(*live_);
 }
 
+void Amg::resync_signals() {
+  hip_check(hipStreamSynchronize(ctx_.stream), "resync signals");
+  seq_expected_ = *h_seq_.p;
+}
+
 HostSignal Amg::next_signal() {
   HostSignal sig;
   if (ctx_.world != 1) return sig;
@@ -1359,8 +1364,7 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
     for (int J = (schedule_all_ ? 0 : L - 1); J < L; ++J)
       if (level(J).plan.N > 0) mg_prepare(J);
   //  a launch that threw after its signal was counted must not leave the host counter ahead of the device's
-  hip_check(hipStreamSynchronize(ctx_.stream), "sync before solve");
-  seq_expected_ = *h_seq_.p;
+  resync_signals();
   // ... nor its reduction tickets half taken: they are re-armed by the last arriver of a launch only (smaller items)
   hip_check(hipMemsetAsync(partials_.p, 0, kReductionHeader * sizeof(double), ctx_.stream), "re-arm tickets");
   if (mg_scratch_.p) hip_check(hipMemsetAsync(mg_scratch_.p, 0, kReductionHeader * sizeof(double), ctx_.stream), "re-arm tickets");
@@ -1434,12 +1438,14 @@ void Amg::solve(const SolveOptions& opt, SolveStats& st) {
 
 double Amg::f0(int l, const double* s_host, double t, double* parts) {
   Level& lv = level(l);
+  resync_signals();
   lv.s_trial.upload(s_host, lv.plan.N);
   return dev_f0(lv, lv.s_trial.p, t, parts, nullptr, phi_cur_.p, Dz_.p);
 }
 
 double Amg::f0_trial(int l, const double* s_ref_host, const double* s_host, double t) {
   Level& lv = level(l);
+  resync_signals();
   lv.s_trial.upload(s_ref_host, lv.plan.N);
   dev_f0(lv, lv.s_trial.p, t, nullptr, nullptr, phi_cur_.p, Dz_.p);     // records phi of the reference iterate
   lv.s_trial.upload(s_host, lv.plan.N);
@@ -1448,6 +1454,7 @@ double Amg::f0_trial(int l, const double* s_ref_host, const double* s_host, doub
 
 void Amg::f1(int l, const double* s_host, double t, double* g_host) {
   Level& lv = level(l);
+  resync_signals();
   lv.s_trial.upload(s_host, lv.plan.N);
   dev_apply(lv, lv.s_trial.p, Dz_.p);
   dev_f1(lv, Dz_.p, t, lv.g_trial.p);
@@ -1457,6 +1464,7 @@ void Amg::f1(int l, const double* s_host, double t, double* g_host) {
 void Amg::f2(int l, const double* s_host, double t, double* avals_host) {
   (void)t;
   Level& lv = level(l);
+  resync_signals();
   lv.s_trial.upload(s_host, lv.plan.N);
   dev_apply(lv, lv.s_trial.p, Dz_.p);
   launch_barrier_f2(ctx_.stream, n_, P_, Dz_.p, w_.p, Y_.p);

@@ -531,6 +531,9 @@ class Amg {
   DevBuf<unsigned long long> seq_dev_;
   PinnedBuf<unsigned long long> h_seq_;
   unsigned long long seq_expected_ = 0;
+  //  entry points call this first: after an exception between counting a signal and enqueuing its launch the host
+  // counter would stay ahead of the device's for ever; one stream synchronisation puts them back in step
+  void resync_signals();
   HostSignal next_signal();           // the signal to attach to a launch (null pair on a sharded context); counts it as expected
   void wait_signal(const char* what); // returns when every signalled launch so far has delivered its results to the host
   // pinned-host twin of a slot of scal_ on a single GPU (the reduction kernels write it themselves: no copy launch);
