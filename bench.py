@@ -142,9 +142,20 @@ def main():
     backend = M.backend_hip(dev)
     sharded = bool(world > 1 and not args.replicas)
     if sharded:      # one solve over all ranks: row blocks + RCCL allreduce
-        if args.comm == "rccl" and not args.rehearse_one_gpu:
-            M.rccl_comm_from_torch(backend, dist)      # the library owns the communicator; torch only carried the 128-byte id
-        else:
+        use_rccl = args.comm == "rccl" and not args.rehearse_one_gpu
+        if use_rccl:
+            # the library owns the communicator; torch only carries the 128-byte id.  All ranks agree on whether it came up: if
+            # any of them could not open librccl / initialise its rank, every rank drops back to the callback path together
+            ok = 1
+            try:
+                M.rccl_comm_from_torch(backend, dist)
+            except Exception as exc:
+                print("bench.py: library-owned RCCL communicator unavailable on rank %d (%r)" % (rank, exc), file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", dev))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            use_rccl = bool(flag.item())
+        if not use_rccl:
             backend.set_comm(rank, world, M.torch_allreduce(dist, dev))
     if sharded and args.solver != "gpu":
         raise SystemExit("bench.py: --solver pcg runs on one GPU")
