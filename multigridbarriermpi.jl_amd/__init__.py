@@ -148,11 +148,17 @@ def rccl_comm_from_torch(backend: "HPCBackend", dist, group=None):
     import torch
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = torch.device("cuda", backend.device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    t = torch.zeros(128, dtype=torch.uint8, device=dev)
+    t = torch.zeros(129, dtype=torch.uint8, device=dev)      # 128 id bytes + "rank 0 got one": every rank reaches the broadcast
     if rank == 0:
-        t = torch.tensor(list(rccl_unique_id()), dtype=torch.uint8, device=dev)
+        try:
+            t = torch.tensor(list(rccl_unique_id()) + [1], dtype=torch.uint8, device=dev)
+        except MGBError:
+            pass
     dist.broadcast(t, src=0, group=group)
-    backend.set_comm_rccl(rank, world, bytes(t.cpu().tolist()))
+    raw = bytes(t.cpu().tolist())
+    if raw[128] != 1:
+        raise MGBError(-2, "rccl_comm_from_torch: rank 0 could not draw an RCCL unique id (librccl not available?)")
+    backend.set_comm_rccl(rank, world, raw[:128])
 
 
 _BACKENDS: Dict[int, HPCBackend] = {}
