@@ -265,6 +265,38 @@ def test_library_owned_rccl_communicator_one_rank(gpu_required):
     assert out[0][1] == 999 * 1000 / 2 and out[0][2] == 1 and out[0][3] == 8000.0 and out[0][4] > 0
 
 
+def _rccl_from_torch_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import mgb_amd as M
+    from mgb_amd import _lib
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        be = M.HPCBackend(0)
+        M.rccl_comm_from_torch(be, dist)            # torch (with its own RCCL) only carries the id; the library opens librccl itself
+        v = M.HPCVector(np.arange(100.0), be)
+        _lib.call("mgb_vec_allreduce_sum", v.handle)
+        t = torch.ones(4, device="cuda:0")
+        dist.all_reduce(t)                          # torch's communicator still works beside the library's
+        q.put((rank, float(v.to_numpy().sum()), float(t.sum().item()), be.comm_stats()["calls"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_library_rccl_beside_torch_distributed(gpu_required):
+    """bench.py's multi-GPU setup in one process: torch.distributed (backend nccl, its bundled RCCL) broadcasts the unique id, the
+    library binds librccl at run time and owns its communicator; both communicators work side by side (world of one rank: the
+    box has one GPU)."""
+    out = _run(_rccl_from_torch_worker, 1)
+    assert out[0][1] == 99 * 100 / 2 and out[0][2] == 4.0 and out[0][3] == 1
+
+
 def test_plan_shards_sum_to_the_full_plan_gloo_world3_uneven():
     """Three ranks: 8 / 32 elements do not divide evenly, the row blocks differ in size and still partition."""
     out = _run(_shard_worker, 3)
