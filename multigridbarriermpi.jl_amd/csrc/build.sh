@@ -6,6 +6,9 @@ OUT="$HERE/../lib"
 mkdir -p "$OUT" "$HERE/_obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 CXXFLAGS="-O3 -std=c++17 -fPIC -mavx2 -mfma -Wall -Wno-unused-result"
+# kernel arguments preloaded into SGPRs at wave launch (gfx940+): the chain kernels start with descriptor -> data, not
+# argument pointer -> descriptor -> data
+PRELOAD="-mllvm -amdgpu-kernarg-preload-count=16"
 HDRS=("$HERE"/*.hpp "$HERE/../../include/mgb_hip.h")
 pids=()
 # compile <object> <command...>: rebuild when the source or any header is newer; a stale object never survives a failed
@@ -29,7 +32,7 @@ compile "$HERE/_obj/kernels.o" "$HERE/kernels.hip" "$HIPCC" --offload-arch=gfx95
 compile "$HERE/_obj/kernels_f32.o" "$HERE/kernels_f32.hip" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS
 compile "$HERE/_obj/mg.o" "$HERE/mg.hip" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS
 compile "$HERE/_obj/amg_mg.o" "$HERE/amg_mg.cpp" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS -x hip
-compile "$HERE/_obj/gpuchol.o" "$HERE/gpuchol.hip" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS
+compile "$HERE/_obj/gpuchol.o" "$HERE/gpuchol.hip" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS $PRELOAD
 compile "$HERE/_obj/amg.o" "$HERE/amg.cpp" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS -x hip
 compile "$HERE/_obj/comm.o" "$HERE/comm.cpp" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS -x hip
 compile "$HERE/_obj/capi.o" "$HERE/capi.cpp" "$HIPCC" --offload-arch=gfx950 $CXXFLAGS -x hip

@@ -40,12 +40,19 @@ void ck(hipError_t e, const char* what) {
 // kernel) slot 8 / 9 also record the earliest STAMP(0) / latest STAMP(7) over ALL workgroups of the launch and which
 // workgroup finished last -- how the off-diagonal tiles were found to bound a panel step (profiles/r2_chol_phase_stamps_L7.txt).
 constexpr int kProfSlots = 10;
+// -DMGB_PROF_LAST_WG (debugging build): the stamps follow the LAST workgroup of a launch (a trailing-matrix tile) instead
+// of workgroup 0 (the pivot workgroup of the first front)
+#ifdef MGB_PROF_LAST_WG
+#define MGB_PROF_WG (gridDim.x - 1)
+#else
+#define MGB_PROF_WG 0
+#endif
 #ifdef MGB_PROF_ALL_WGS
 #define STAMP(k)                                                                                   \
   do {                                                                                             \
     if (prof && threadIdx.x == 0) {                                                                \
       const long long now_ = wall_clock64();                                                       \
-      if (blockIdx.x == 0) prof[k] = now_;                                                         \
+      if (blockIdx.x == MGB_PROF_WG) prof[k] = now_;                                               \
       if ((k) == 0) atomicMin((unsigned long long*)&prof[8], (unsigned long long)now_);            \
       if ((k) == 7) atomicMax((unsigned long long*)&prof[9], (unsigned long long)now_ * 65536ull + (blockIdx.x & 65535u)); \
     }                                                                                              \
@@ -53,7 +60,7 @@ constexpr int kProfSlots = 10;
 #else
 #define STAMP(k)                                                                   \
   do {                                                                             \
-    if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[k] = wall_clock64();     \
+    if (prof && blockIdx.x == MGB_PROF_WG && threadIdx.x == 0) prof[k] = wall_clock64(); \
   } while (0)
 #endif
 
@@ -70,8 +77,8 @@ __device__ inline double readlane_f64(double v, int lane) {
 // constant-lane v_readlane, every lane forms 1/L[k][k], L[k+1][k], 1/L[k+1][k+1], the owning half computes its
 // two multipliers per row, and these go through a 64-entry LDS line (one write, then conflict-free broadcast
 // reads; LDS executes a wave's accesses in order, so no barrier is needed): 16 LDS round trips per block
-// instead of a v_readlane/s_nop pair per ENTRY.  Entries right of the diagonal of a row are don't-care (their
-// multipliers are forced to 0 once k passes the row), so the update is branch-free.  The diagonal slot keeps
+// instead of a v_readlane/s_nop pair per ENTRY.  Entries right of the diagonal of a row are don't-care (a finished row
+// keeps "updating" them with whatever its multiplier slot holds), so the update is branch-free.  The diagonal slot keeps
 // 1/L[k][k] (L[k][k] itself is never needed again): every consumer (panel TRSM, backward sweep) is a
 // substitution that multiplies by it.  Stores the block row-major to lp[32 i + j] and column-major behind it
 // (zero above the diagonal).
@@ -82,42 +89,61 @@ __device__ inline double readlane_f64(double v, int lane) {
 using lds_f64 = __attribute__((address_space(3))) double*;
 using lds_cf64 = const __attribute__((address_space(3))) double*;
 
-// the 16 rounds of the in-register factorisation: straight-line code, or (BRK) with an exit test per round
+// 1 / sqrt(x): v_rsq_f64 and one Newton-type correction, the arithmetic of the device library's rsqrt() without its
+// fix-up of x = 0 / inf (three more instructions on the single-wave critical path; such pivots are flagged by the caller)
+__device__ __forceinline__ double rsq_refined(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(y * -x, y, 1.0);
+  return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+
+// the 16 rounds of the in-register factorisation: straight-line code, or (BRK) with an exit test per round.
+// ONE wave issues everything here, one instruction per ~4.5 cycles, and the rounds were measured at the product of the two
+// (675 cycles = ~135 instructions per round), so the code is written for instruction count:
+//   * no pivot test inside the round: a pivot that is not positive and finite turns its reciprocal root (and everything
+//     after it) into NaN / inf, which `chk` collects with four instructions per round (x * 0 is NaN for both);
+//   * rows above the pivot keep whatever the update leaves in their don't-care entries right of the diagonal (no
+//     multiplier is forced to zero): nothing reads those, the store masks them;
+//   * the half of the wave that does not own the pivot columns is switched off by the execution mask instead of
+//     selecting per value.
 template <bool BRK>
-__device__ inline void factor_rounds(double (&a)[PB / 2], lds_f64 col, int i, int h, bool& bad, int kw) {
+__device__ inline void factor_rounds(double (&a)[PB / 2], lds_f64 col, int i, int h, double& chk, int kw) {
+  // No control flow inside a round (the compiler keeps a[] as one register tuple and copied all of it around every
+  // masked region): the multipliers are computed by every lane and SELECTED by the owning half, the other half writes
+  // its (meaningless) pair to a dummy line behind the broadcast line, and the update of the h = 1 lanes' pivot-slot
+  // columns in the even rounds is switched off in the h = 0 lanes by a zero multiplier.
+  // LDS: col[0..63] multipliers (row i at 2 i), col[64..127] dummy line, col[128..159] the reciprocal pivots.
+  const bool h0 = h == 0;
+  const double hm = h0 ? 0.0 : 1.0;
+  lds_f64 wr[2] = {col + (h0 ? 0 : 64) + 2 * i, col + (h0 ? 64 : 0) + 2 * i};      // where this lane writes in even / odd rounds
 #pragma unroll
   for (int kk = 0; kk < PB / 2; ++kk) {
     const int k = 2 * kk, hk = kk & 1, mk = kk >> 1;
     if (BRK && k >= kw) break;
-    double akk = readlane_f64(a[2 * mk], k + 32 * hk);
+    const double akk = readlane_f64(a[2 * mk], k + 32 * hk);
     const double ak1k = readlane_f64(a[2 * mk], k + 1 + 32 * hk);
     const double ak1k1 = readlane_f64(a[2 * mk + 1], k + 1 + 32 * hk);
-    if (!(akk > 0.0) || !isfinite(akk)) {
-      bad = true;
-      akk = 1.0;
-    }
-    const double rd0 = rsqrt(akk);              // 1 / L[k][k]
+    const double rd0 = rsq_refined(akk);        // 1 / L[k][k]
     const double l10 = ak1k * rd0;              // L[k+1][k]
-    double d1 = fma(-l10, l10, ak1k1);
-    if (!(d1 > 0.0) || !isfinite(d1)) {
-      bad = true;
-      d1 = 1.0;
-    }
-    const double rd1 = rsqrt(d1);               // 1 / L[k+1][k+1]
-    if (h == hk) {
-      const double l0 = (i > k) ? a[2 * mk] * rd0 : 0.0;
-      const double l1 = (i > k + 1) ? fma(-l0, l10, a[2 * mk + 1]) * rd1 : 0.0;
-      col[2 * i] = l0;
-      col[2 * i + 1] = l1;
-      a[2 * mk] = (i == k) ? rd0 : l0;
-      a[2 * mk + 1] = (i == k + 1) ? rd1 : l1;
-    }
+    const double d1 = fma(-l10, l10, ak1k1);
+    const double rd1 = rsq_refined(d1);         // 1 / L[k+1][k+1]
+    chk = fma(akk + d1, 0.0, chk);
+    chk = fma(rd0 + rd1, 0.0, chk);
+    const double l0 = a[2 * mk] * rd0;
+    const double l1 = fma(-l0, l10, a[2 * mk + 1]) * rd1;
+    wr[hk][0] = l0;
+    wr[hk][1] = l1;
+    col[128 + k] = rd0;       // every lane, the same values: the diagonal slots are patched from here after the rounds
+    col[128 + k + 1] = rd1;
+    const bool own = hk ? !h0 : h0;
+    a[2 * mk] = own ? l0 : a[2 * mk];
+    a[2 * mk + 1] = own ? l1 : a[2 * mk + 1];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const double li0 = col[2 * i], li1 = col[2 * i + 1];
     if (hk == 0) {      // the pair (k+2, k+3) lives in the h = 1 lanes at the same register slots
-      const double m0 = (h == 1) ? li0 : 0.0, m1 = (h == 1) ? li1 : 0.0;
+      const double m0 = li0 * hm, m1 = li1 * hm;
       a[2 * mk] = fma(-m1, col[2 * (k + 2) + 1], fma(-m0, col[2 * (k + 2)], a[2 * mk]));
       a[2 * mk + 1] = fma(-m1, col[2 * (k + 3) + 1], fma(-m0, col[2 * (k + 3)], a[2 * mk + 1]));
     }
@@ -152,12 +178,14 @@ __device__ __forceinline__ void factor_diag_block(const double* D, int kw, doubl
       if (i < kw && j < kw && j <= i) v = D[i * LP + j];
       a[q] = v;
     }
-    bool bad = false;
+    double chk = 0.0;
     lds_f64 col = (lds_f64)Lo;      // the broadcast line aliases the output block, which is only written after the loop
-    if (EXIT) factor_rounds<true>(a, col, i, h, bad, kw);
-    else factor_rounds<false>(a, col, i, h, bad, PB);
+    if (EXIT) factor_rounds<true>(a, col, i, h, chk, kw);
+    else factor_rounds<false>(a, col, i, h, chk, PB);
     STAMP(6);
-    if (bad && tid == 0) atomicOr(fail, 1);
+    if (chk != chk && tid == 0) atomicOr(fail, 1);
+    // the reciprocal pivot of this lane's row (rows of the identity padding the rounds never reached keep their 1)
+    const double rdv = (!EXIT || i < ((kw + 1) & ~1)) ? col[128 + i] : 1.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -169,6 +197,8 @@ __device__ __forceinline__ void factor_diag_block(const double* D, int kw, doubl
         Lo[i * LP + j] = (j <= i) ? a[q] : 0.0;
       }
     }
+    // the diagonal slot holds 1 / L[i][i]: patched behind the row stores (LDS keeps a wave's accesses in order)
+    Lo[PACKED ? lo_packed(i, i) : i * LP + i] = rdv;
   }
   __syncthreads();
   if (lp == nullptr) return;      // workgroup-uniform: the caller keeps the factor in Lo only
@@ -196,9 +226,10 @@ __device__ __forceinline__ void factor_block_wave0(const double* D, int kw, doub
     if (i < kw && j < kw && j <= i) v = D[i * LP + j];
     a[q] = v;
   }
-  bool bad = false;
-  factor_rounds<false>(a, (lds_f64)Lo, i, h, bad, PB);
-  if (bad && tid == 0) atomicOr(fail, 1);
+  double chk = 0.0;
+  factor_rounds<false>(a, (lds_f64)Lo, i, h, chk, PB);
+  if (chk != chk && tid == 0) atomicOr(fail, 1);
+  const double rdv = ((lds_f64)Lo)[128 + i];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -206,6 +237,7 @@ __device__ __forceinline__ void factor_block_wave0(const double* D, int kw, doub
     const int j = 4 * (q >> 1) + 2 * h + (q & 1);
     Lo[i * LP + j] = (j <= i) ? a[q] : 0.0;
   }
+  Lo[i * LP + i] = rdv;
 }
 
 // Start of a height: workgroup = 32 columns x 256 rows of one front, in gather form.  (1) every lower entry (and the
@@ -781,6 +813,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       if (r0 + r <= nf && okc) F[(long long)ld * (r0 + r) + col] = ATI[q * TP + r];
     }
   }
+  STAMP(5);
   // rank-64 update of the C tile (layout and operand order of front_step)
   const double* LI = ATI + 16 * w + li + lk * TP;
   const double* LJ = (diag ? ATI : ATJ) + li + lk * TP;
@@ -794,6 +827,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int bj = 0; bj < 4; ++bj)
       acc[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(LJ[4 * ks * TP + 16 * bj], bv, acc[bj], 0, 0, 0);
   }
+  STAMP(6);
 #pragma unroll
   for (int bj = 0; bj < 4; ++bj)
 #pragma unroll
