@@ -430,31 +430,70 @@ __device__ __forceinline__ void trsm_quad_load(double (&col)[PB / 4], double& di
 
 // software pipeline: the entries of column J + 2 are requested before column J is consumed (two columns in flight cover
 // the LDS latency of the short steps); the empty asm keeps the compiler from hoisting ALL columns (it did: 372 VGPRs)
-// or sinking the loads next to their uses
-template <int J, bool EXIT, bool PACKED>
-__device__ __forceinline__ void trsm_quad_step(double (&f)[PB / 4], const double* Lq, int c4, int kw, const double (&col)[PB / 4],
-                                               double diag, const double (&col1)[PB / 4], double diag1) {
+// or sinking the loads next to their uses.
+// NB row blocks (16 rows each, their own f / x registers) are solved side by side against the same columns: a single block
+// is bound by the latency of its dependent chain (scale, broadcast, update: ~125 cycles per step against ~85 of issue),
+// so a second and a third block ride in the gaps -- three blocks take about as long as one.
+// The solved entry goes to x[kk] of its owner by a multiply-add with the lane's 0 / 1 owner flag (one instruction; the
+// select it replaces took two, and two more for the lane's own entry of the column, which (not PACKED) needs none: left
+// of the diagonal the stored factor holds zeros, and the owner's f[kk] -- "updated" with the reciprocal pivot -- is dead
+// from here on).
+template <int J, int NB, bool EXIT, bool PACKED>
+__device__ __forceinline__ void trsm_quad_step(double (&f)[NB][PB / 4], double (&x)[NB][PB / 4], const double (&e)[4], const double* Lq,
+                                               int c4, int kw, const double (&col)[PB / 4], double diag, const double (&col1)[PB / 4],
+                                               double diag1) {
   if constexpr (J < PB) {
     constexpr int owner = J & 3, kk = J >> 2;
-    if (EXIT && (J & 7) == 0 && J >= kw) return;      // identity padding (workgroup-uniform)
+    if (EXIT && (J & 7) == 0 && J >= kw) {      // identity padding (workgroup-uniform): the remaining entries pass through
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int k = kk; k < PB / 4; ++k) x[b][k] = f[b][k];
+      return;
+    }
     double col2[PB / 4], diag2 = 0.0;
     trsm_quad_load<J + 2, PACKED>(col2, diag2, Lq, c4);
     asm volatile("" ::: "memory");
-    const double fj = quad_bcast<owner>(f[kk] * diag);
-    const double lkk = (c4 > owner) ? col[kk] : 0.0;     // entries of this lane left of / on the diagonal: no update
-    f[kk] = (c4 == owner) ? fj : fma(-fj, lkk, f[kk]);
+    const double lkk = PACKED ? ((c4 > owner) ? col[kk] : 0.0) : col[kk];
 #pragma unroll
-    for (int k = kk + 1; k < PB / 4; ++k) f[k] = fma(-fj, col[k], f[k]);
-    trsm_quad_step<J + 1, EXIT, PACKED>(f, Lq, c4, kw, col1, diag1, col2, diag2);
+    for (int b = 0; b < NB; ++b) {
+      const double fj = quad_bcast<owner>(f[b][kk] * diag);
+      x[b][kk] = fma(fj, e[owner], x[b][kk]);
+      f[b][kk] = fma(-fj, lkk, f[b][kk]);
+#pragma unroll
+      for (int k = kk + 1; k < PB / 4; ++k) f[b][k] = fma(-fj, col[k], f[b][k]);
+    }
+    trsm_quad_step<J + 1, NB, EXIT, PACKED>(f, x, e, Lq, c4, kw, col1, diag1, col2, diag2);
   }
+}
+
+// f (in): this lane's entries m = c4, c4 + 4, .. of NB rows; (out): the solved entries
+template <int NB, bool EXIT = false, bool PACKED = false>
+__device__ __forceinline__ void trsm_quad_n(double (&f)[NB][PB / 4], const double* Lq, int c4, int kw = PB) {
+  double col[PB / 4], diag = 0.0, col1[PB / 4], diag1 = 0.0, x[NB][PB / 4], e[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) e[o] = (c4 == o) ? 1.0 : 0.0;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int k = 0; k < PB / 4; ++k) x[b][k] = 0.0;
+  trsm_quad_load<0, PACKED>(col, diag, Lq, c4);
+  trsm_quad_load<1, PACKED>(col1, diag1, Lq, c4);
+  trsm_quad_step<0, NB, EXIT, PACKED>(f, x, e, Lq, c4, kw, col, diag, col1, diag1);
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int k = 0; k < PB / 4; ++k) f[b][k] = x[b][k];
 }
 
 template <bool EXIT = false, bool PACKED = false>
 __device__ __forceinline__ void trsm_quad(double (&f)[PB / 4], const double* Lq, int c4, int kw = PB) {
-  double col[PB / 4], diag = 0.0, col1[PB / 4], diag1 = 0.0;
-  trsm_quad_load<0, PACKED>(col, diag, Lq, c4);
-  trsm_quad_load<1, PACKED>(col1, diag1, Lq, c4);
-  trsm_quad_step<0, EXIT, PACKED>(f, Lq, c4, kw, col, diag, col1, diag1);
+  double g[1][PB / 4];
+#pragma unroll
+  for (int k = 0; k < PB / 4; ++k) g[0][k] = f[k];
+  trsm_quad_n<1, EXIT, PACKED>(g, Lq, c4, kw);
+#pragma unroll
+  for (int k = 0; k < PB / 4; ++k) f[k] = g[0][k];
 }
 
 // X L11' = A for the 64 rows of a staged panel block AT (AT[q * TP + r] = (row r, panel column q)), in place, by all four
@@ -468,6 +507,24 @@ __device__ __forceinline__ void trsm_block64(double* AT, int TP, const double* L
   trsm_quad<EXIT, PACKED>(f, Lq, c4, kw);
 #pragma unroll
   for (int k = 0; k < PB / 4; ++k) AT[(c4 + 4 * k) * TP + r] = f[k];
+}
+
+// the same for the two panel blocks of an off-diagonal tile at once (rows 16 w .. of both, side by side in every wave)
+template <bool EXIT = false>
+__device__ __forceinline__ void trsm_block64_pair(double* ATI, double* ATJ, int TP, const double* Lq, int kw = PB) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = 16 * w + (lane >> 2), c4 = lane & 3;
+  double f[2][PB / 4];
+#pragma unroll
+  for (int k = 0; k < PB / 4; ++k) {
+    f[0][k] = ATI[(c4 + 4 * k) * TP + r];
+    f[1][k] = ATJ[(c4 + 4 * k) * TP + r];
+  }
+  trsm_quad_n<2, EXIT, false>(f, Lq, c4, kw);
+#pragma unroll
+  for (int k = 0; k < PB / 4; ++k) {
+    ATI[(c4 + 4 * k) * TP + r] = f[0][k];
+    ATJ[(c4 + 4 * k) * TP + r] = f[1][k];
+  }
 }
 
 // Critical path of a panel step, run by a dedicated workgroup per front: rows k1..k1+31 of the panel are solved
@@ -579,8 +636,8 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 3))) void
   __syncthreads();
   STAMP(1);
   // X L11' = A for the rows of I (and of J off the diagonal) by all four waves, four lanes per row (trsm_block64)
-  trsm_block64(ATI, TP, Lc);
-  if (!diag) trsm_block64(ATJ, TP, Lc);
+  if (diag) trsm_block64(ATI, TP, Lc);
+  else trsm_block64_pair(ATI, ATJ, TP, Lc);
   __syncthreads();
   if (t.tj == 0) {      // finished rows of L go to the mirrored (upper) half: row r0 + r, 32 consecutive entries
     for (int idx = tid; idx < TS * PB; idx += TB) {
@@ -740,28 +797,20 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   if (w == 0) {
     factor_block_wave0(D, kw2, Lo, fail);      // L22
   } else {
-    // 16-row blocks of the panel blocks: X1 = A1 L11^-T in place, then A2 -= X1 L21' (both wave-local)
+    // 16-row blocks of the panel blocks: X1 = A1 L11^-T in place, then A2 -= X1 L21' (both wave-local).  Wave w takes
+    // the blocks w - 1, w + 2, w + 5 (of 2 / 4 / 8: pivot workgroup, diagonal tile, off-diagonal tile) and solves them
+    // side by side (trsm_quad_n: three blocks take about as long as one, and wave 0 is busy with the factor that long)
     const int nblk = is_piv ? 2 : (diag ? 4 : 8);
-    for (int b = w - 1; b < nblk; b += 3) {
-      double* AT = (b < 4) ? ATI : ATJ;
-      const int rb = 16 * (b & 3), r = rb + (lane >> 2);
-      double g[PB / 4];
-#pragma unroll
-      for (int k = 0; k < PB / 4; ++k) g[k] = AT[(c4 + 4 * k) * TP + r];
-      trsm_quad(g, Lc1, c4);
-#pragma unroll
-      for (int k = 0; k < PB / 4; ++k) AT[(c4 + 4 * k) * TP + r] = g[k];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    auto block_at = [&](int b) { return ((b < 4) ? ATI : ATJ) + 16 * (b & 3); };      // rows of block b: + r
+    auto update2 = [&](double* AB) {      // A2 -= X1 L21' for the 16 rows at AB
       v4f64 a2[2];
 #pragma unroll
       for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) a2[bj][reg] = AT[(PB + 16 * bj + lk + 4 * reg) * TP + rb + li];
+        for (int reg = 0; reg < 4; ++reg) a2[bj][reg] = AB[(PB + 16 * bj + lk + 4 * reg) * TP + li];
 #pragma unroll
       for (int ks = 0; ks < PB / 4; ++ks) {
-        const double bv = -AT[(4 * ks + lk) * TP + rb + li];
+        const double bv = -AB[(4 * ks + lk) * TP + li];
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj)
           a2[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(P[(16 * bj + li) * LP + 4 * ks + lk], bv, a2[bj], 0, 0, 0);
@@ -769,7 +818,44 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
       for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) AT[(PB + 16 * bj + lk + 4 * reg) * TP + rb + li] = a2[bj][reg];
+        for (int reg = 0; reg < 4; ++reg) AB[(PB + 16 * bj + lk + 4 * reg) * TP + li] = a2[bj][reg];
+    };
+    const int b0 = w - 1, r = lane >> 2;
+    if (b0 + 3 >= nblk) {      // one block (wave-uniform; the pivot workgroups, whose factor is the critical path of the chain)
+      if (b0 < nblk) {
+        double* AB = block_at(b0);
+        double g[PB / 4];
+#pragma unroll
+        for (int k = 0; k < PB / 4; ++k) g[k] = AB[(c4 + 4 * k) * TP + r];
+        trsm_quad(g, Lc1, c4);
+#pragma unroll
+        for (int k = 0; k < PB / 4; ++k) AB[(c4 + 4 * k) * TP + r] = g[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        update2(AB);
+      }
+    } else {                   // two or three blocks: a missing third one is solved as zeros and not stored
+      const bool third = b0 + 6 < nblk;
+      double* AB[3] = {block_at(b0), block_at(b0 + 3), block_at(third ? b0 + 6 : b0)};
+      double g[3][PB / 4];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int k = 0; k < PB / 4; ++k) g[q][k] = (q < 2 || third) ? AB[q][(c4 + 4 * k) * TP + r] : 0.0;
+      trsm_quad_n<3>(g, Lc1, c4);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (q < 2 || third) {
+#pragma unroll
+          for (int k = 0; k < PB / 4; ++k) AB[q][(c4 + 4 * k) * TP + r] = g[q][k];
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      update2(AB[0]);
+      update2(AB[1]);
+      if (third) update2(AB[2]);
     }
   }
   __syncthreads();
@@ -785,8 +871,8 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
   }
   __syncthreads();
-  trsm_block64(ATI + PB * TP, TP, Lc2);      // X2 = (A2 - X1 L21') L22^-T
-  if (!diag) trsm_block64(ATJ + PB * TP, TP, Lc2);
+  if (diag) trsm_block64(ATI + PB * TP, TP, Lc2);      // X2 = (A2 - X1 L21') L22^-T
+  else trsm_block64_pair(ATI + PB * TP, ATJ + PB * TP, TP, Lc2);
   __syncthreads();
   STAMP(4);
   if (is_piv) {
@@ -975,8 +1061,8 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   for (int idx = tid; idx < PB * PB; idx += TB) Lc[lq_index(idx % PB, idx / PB)] = Lo[(idx % PB) * LP + idx / PB];     // L[m][j], quad order
   __syncthreads();
   STAMP(2);
-  trsm_block64<NARROW>(ATI, TP, Lc, kw);      // all four waves, four lanes per row (see front_step)
-  if (!diag) trsm_block64<NARROW>(ATJ, TP, Lc, kw);
+  if (diag) trsm_block64<NARROW>(ATI, TP, Lc, kw);      // all four waves, four lanes per row (see front_step)
+  else trsm_block64_pair<NARROW>(ATI, ATJ, TP, Lc, kw);
   __syncthreads();
   if (t.tj == 0) {
     for (int idx = tid; idx < TS * PB; idx += TB) {
