@@ -1233,8 +1233,11 @@ template <int NT>
 __global__ __launch_bounds__(NT) void backward_kernel(const GNode* __restrict__ nodes, const int* __restrict__ list,
                                                        const int* __restrict__ bdry_all, const double* __restrict__ fronts,
                                                        const double* __restrict__ linv, const int* __restrict__ perm,
-                                                       const double* __restrict__ rect, int use_rect, double* y, double* x) {
+                                                       const double* __restrict__ rect, int use_rect, double* y, double* x,
+                                                       long long* prof) {
   extern __shared__ double sh[];      // u[ns] | xb[nb] | red[NT]
+  STAMP(0);      // stamps: 1 right-hand side staged, 2 boundary part subtracted, 3 / 4 / 5 the last panel's substitution, its
+                 // barrier, its update of the earlier columns, 6 all panels done, 7 solution stored
   const GNode nd = nodes[blockIdx.x];      // per-launch copy in launch order: one descriptor round trip, not two
   (void)list;
   const int nf = nd.nf, ns = nd.ns, nb = nf - ns, ld = nf + 1, tid = threadIdx.x;
@@ -1243,6 +1246,7 @@ __global__ __launch_bounds__(NT) void backward_kernel(const GNode* __restrict__ 
   double* xb = sh + ns;
   double* red = sh + nf;
   for (int i = tid; i < ns; i += NT) u[i] = F[(long long)ld * nf + i] - ((use_rect && nb > 0) ? rect[nd.first + i] : 0.0);
+  STAMP(1);
   if (!use_rect && nb > 0) {      // workgroup-uniform
     const int* bd = bdry_all + nd.bofs;
     for (int i = tid; i < nb; i += NT) xb[i] = y[bd[i]];
@@ -1254,6 +1258,7 @@ __global__ __launch_bounds__(NT) void backward_kernel(const GNode* __restrict__ 
     }
   }
   __syncthreads();
+  STAMP(2);
   const int npanel = (ns + PB - 1) / PB;
   for (int pp = npanel - 1; pp >= 0; --pp) {
     const int k0 = pp * PB, kw = min(PB, ns - k0), k1 = k0 + kw;
@@ -1272,8 +1277,10 @@ __global__ __launch_bounds__(NT) void backward_kernel(const GNode* __restrict__ 
         uc = (c == m) ? xm : fma(-lc[m], xm, uc);                 // lanes c > m: lc[m] == 0
       }
       if (tid < kw) u[k0 + c] = uc;
+      if (pp == npanel - 1) STAMP(3);
     }
     __syncthreads();
+    if (pp == npanel - 1) STAMP(4);
     if (k0 > 0) {
       const int jw = min(NT, (k0 + 63) & ~63), nsl = NT / jw;
       for (int jb = 0; jb < k0; jb += jw) {
@@ -1293,12 +1300,15 @@ __global__ __launch_bounds__(NT) void backward_kernel(const GNode* __restrict__ 
       }
       __syncthreads();
     }
+    if (pp == npanel - 1) STAMP(5);
   }
+  STAMP(6);
   for (int i = tid; i < ns; i += NT) {
     const double v = u[i];
     y[nd.first + i] = v;
     x[perm[nd.first + i]] = v;
   }
+  STAMP(7);
 }
 
 // Split factorisation: the Schur complement of a subtree root -- lower triangle of the boundary block of its front plus
@@ -1856,7 +1866,7 @@ void GpuChol::enqueue_forward(hipStream_t st, const std::vector<HeightPlan>& pla
   }
 }
 
-void GpuChol::enqueue_backward(hipStream_t st, const std::vector<HeightPlan>& plan, double* d_x, KernelTimer* tm) {
+void GpuChol::enqueue_backward(hipStream_t st, const std::vector<HeightPlan>& plan, double* d_x, KernelTimer* tm, int* nprof) {
   for (int h = (int)plan.size() - 1; h >= 0; --h) {
     const HeightPlan& hp = plan[h];
     const int use_rect = hp.rect.cnt ? 1 : 0;
@@ -1870,11 +1880,11 @@ void GpuChol::enqueue_backward(hipStream_t st, const std::vector<HeightPlan>& pl
     if (hp.max_nf > 384)
       hipLaunchKernelGGL(backward_kernel<1024>, dim3(hp.nodes.cnt), dim3(1024), (size_t)(hp.max_nf + 1024 + PB) * sizeof(double),
                          st, d_hnodes_ + hp.nodes.ofs, d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_linv_, d_perm_, d_rect_, use_rect, d_y_,
-                         d_x);
+                         d_x, (d_prof_ && nprof) ? d_prof_ + kProfSlots * ((*nprof)++) : nullptr);
     else
       hipLaunchKernelGGL(backward_kernel<256>, dim3(hp.nodes.cnt), dim3(256), (size_t)(hp.max_nf + 256 + PB) * sizeof(double),
                          st, d_hnodes_ + hp.nodes.ofs, d_lists_ + hp.nodes.ofs, d_bdry_, d_fronts_, d_linv_, d_perm_, d_rect_, use_rect, d_y_,
-                         d_x);
+                         d_x, (d_prof_ && nprof) ? d_prof_ + kProfSlots * ((*nprof)++) : nullptr);
     if (tm) tm->end(st);
   }
 }
@@ -1923,7 +1933,7 @@ void GpuChol::factor_solve_split(hipStream_t st, double* d_vals, const double* d
 void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, double* d_x, KernelTimer* tm) {
   int nprof = 0;
   enqueue_forward(st, plan_, d_vals, d_b, tm, nprof);
-  enqueue_backward(st, plan_, d_x, tm);
+  enqueue_backward(st, plan_, d_x, tm, &nprof);
   ck(hipGetLastError(), "factor_solve launches");
   if (d_prof_) {      // debugging aid: phase stamps of workgroup 0 of every factorisation launch, in units of 10 ns
     ck(hipStreamSynchronize(st), "prof sync");

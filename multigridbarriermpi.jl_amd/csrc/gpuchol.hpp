@@ -128,7 +128,7 @@ class GpuChol {
   struct HeightPlan;
   void enqueue_forward(hipStream_t st, const std::vector<HeightPlan>& plan, const double* d_vals, const double* d_b, KernelTimer* tm,
                        int& nprof);
-  void enqueue_backward(hipStream_t st, const std::vector<HeightPlan>& plan, double* d_x, KernelTimer* tm);
+  void enqueue_backward(hipStream_t st, const std::vector<HeightPlan>& plan, double* d_x, KernelTimer* tm, int* nprof = nullptr);
   void factor_solve_split(hipStream_t st, double* d_vals, const double* d_b, double* d_x, KernelTimer* tm, bool values_summed,
                           bool x_local);
   int* d_kind_orig_ = nullptr;
