@@ -14,6 +14,7 @@
 #include "amg.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -47,11 +48,24 @@ constexpr int kProfSlots = 10;
 #else
 #define MGB_PROF_WG 0
 #endif
+// -DMGB_PROF_PER_WG (with -DMGB_PROF_ALL_WGS): start and end of EVERY workgroup of every stamped launch, printed as a
+// per-launch summary (dispatch stagger, duration spread, the slowest workgroups)
+#ifdef MGB_PROF_PER_WG
+constexpr int kProfMaxWg = 2048;
+__device__ long long* g_wgprof = nullptr;
+__device__ long long* g_prof_base = nullptr;
+#define STAMP_WG(k, now_)                                                                                               \
+  if (((k) == 0 || (k) == 7) && g_wgprof && blockIdx.x < kProfMaxWg)                                                     \
+    g_wgprof[(((prof - g_prof_base) / kProfSlots) * kProfMaxWg + blockIdx.x) * 2 + ((k) == 7)] = now_;
+#else
+#define STAMP_WG(k, now_)
+#endif
 #ifdef MGB_PROF_ALL_WGS
 #define STAMP(k)                                                                                   \
   do {                                                                                             \
     if (prof && threadIdx.x == 0) {                                                                \
       const long long now_ = wall_clock64();                                                       \
+      STAMP_WG(k, now_)                                                                            \
       if (blockIdx.x == MGB_PROF_WG) prof[k] = now_;                                               \
       if ((k) == 0) atomicMin((unsigned long long*)&prof[8], (unsigned long long)now_);            \
       if ((k) == 7) atomicMax((unsigned long long*)&prof[9], (unsigned long long)now_ * 65536ull + (blockIdx.x & 65535u)); \
@@ -639,7 +653,10 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 3))) void
   if (diag) trsm_block64(ATI, TP, Lc);
   else trsm_block64_pair(ATI, ATJ, TP, Lc);
   __syncthreads();
-  if (t.tj == 0) {      // finished rows of L go to the mirrored (upper) half: row r0 + r, 32 consecutive entries
+  // finished rows of L go to the mirrored (upper) half (row r0 + r, 32 consecutive entries), stored by the LAST tile of the
+  // row block -- its diagonal tile, which stages one panel block where an off-diagonal tile stages and solves two and is what
+  // the launch waits for (the tj == 0 tiles did this before: 1.5 us on the slowest workgroups)
+  if (t.tj == min((int)t.ti, max(1, (nf - k1 + TS - 1) / TS) - 1)) {
     for (int idx = tid; idx < TS * PB; idx += TB) {
       const int r = idx / PB, m = idx % PB;
       if (r0 + r <= nf && m < kw) F[(long long)ld * (r0 + r) + k0 + m] = ATI[m * TP + r];
@@ -891,7 +908,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     STAMP(7);
     return;
   }
-  if (t.tj == 0) {      // finished rows of L (both panels) go to the mirrored half
+  if (t.tj == min((int)t.ti, max(1, (nf - k2 + TS - 1) / TS) - 1)) {      // finished rows of L (both panels) go to the mirrored half: the row block's last (diagonal) tile, see front_step
     for (int idx = tid; idx < TS * 2 * PB; idx += TB) {
       const int r = idx / (2 * PB), q = idx % (2 * PB);
       const int col = (q < PB) ? k0 + q : k1 + q - PB;
@@ -1064,7 +1081,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if (diag) trsm_block64<NARROW>(ATI, TP, Lc, kw);      // all four waves, four lanes per row (see front_step)
   else trsm_block64_pair<NARROW>(ATI, ATJ, TP, Lc, kw);
   __syncthreads();
-  if (t.tj == 0) {
+  if (t.tj == min((int)t.ti, max(1, (nf - k1 + TS - 1) / TS) - 1)) {      // the row block's last (diagonal) tile, see front_step
     for (int idx = tid; idx < TS * PB; idx += TB) {
       const int r = idx / PB, m = idx % PB;
       if (r0 + r <= nf && m < kw) F[(long long)ld * (r0 + r) + m] = ATI[m * TP + r];
@@ -1771,6 +1788,17 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
   if (std::getenv("MGB_CHOL_PROF")) {
     ck(hipMalloc((void**)&d_prof_, (size_t)kProfSlots * launches_ * sizeof(long long)), "hipMalloc prof");
     allocs_.push_back(d_prof_);
+#ifdef MGB_PROF_PER_WG
+    {
+      long long* wg = nullptr;
+      ck(hipMalloc((void**)&wg, (size_t)launches_ * kProfMaxWg * 2 * sizeof(long long)), "hipMalloc wgprof");
+      allocs_.push_back(wg);
+      ck(hipMemset(wg, 0, (size_t)launches_ * kProfMaxWg * 2 * sizeof(long long)), "memset wgprof");
+      ck(hipMemcpyToSymbol(HIP_SYMBOL(g_wgprof), &wg, sizeof(wg)), "symbol wgprof");
+      ck(hipMemcpyToSymbol(HIP_SYMBOL(g_prof_base), &d_prof_, sizeof(d_prof_)), "symbol prof base");
+      d_wgprof_ = wg;
+    }
+#endif
     {
       std::vector<long long> init((size_t)kProfSlots * launches_, 0LL);
       for (int q = 0; q < launches_; ++q) init[(size_t)kProfSlots * q + 8] = -1LL;
@@ -1950,6 +1978,43 @@ void GpuChol::enqueue(hipStream_t st, const double* d_vals, const double* d_b, d
       std::fprintf(stderr, "  | all wgs %6.2f (last: wg %5d)  since prev end %6.2f\n", (end_q - v[8]) * 0.01,
                    (int)((unsigned long long)v[9] & 65535ull), pv ? (v[8] - end_p) * 0.01 : 0.0);
     }
+#ifdef MGB_PROF_PER_WG
+    if (d_wgprof_) {
+      std::vector<long long> wg((size_t)nprof * kProfMaxWg * 2);
+      ck(hipMemcpy(wg.data(), d_wgprof_, wg.size() * sizeof(long long), hipMemcpyDeviceToHost), "wgprof D2H");
+      std::fprintf(stderr, "[mgb chol wgs] launch: workgroups | start of the last one after the first | duration min / median / max | span | slowest: wg(start, duration) (us)\n");
+      for (int q = 0; q < nprof; ++q) {
+        std::vector<std::array<double, 3>> v;      // start, duration, id
+        long long t0 = -1;
+        for (int b = 0; b < kProfMaxWg; ++b) {
+          const long long st0 = wg[((size_t)q * kProfMaxWg + b) * 2], en = wg[((size_t)q * kProfMaxWg + b) * 2 + 1];
+          if (st0 == 0 || en == 0) continue;
+          if (t0 < 0 || st0 < t0) t0 = st0;
+        }
+        double last_start = 0, span = 0;
+        for (int b = 0; b < kProfMaxWg; ++b) {
+          const long long st0 = wg[((size_t)q * kProfMaxWg + b) * 2], en = wg[((size_t)q * kProfMaxWg + b) * 2 + 1];
+          if (st0 == 0 || en == 0) continue;
+          v.push_back({(st0 - t0) * 0.01, (en - st0) * 0.01, (double)b});
+          last_start = std::max(last_start, (st0 - t0) * 0.01);
+          span = std::max(span, (en - t0) * 0.01);
+        }
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end(), [](const auto& a, const auto& b2) { return a[1] < b2[1]; });
+        std::fprintf(stderr, "[mgb chol wgs] %3d: %5zu | %6.2f | %6.2f %6.2f %6.2f | %6.2f |", q, v.size(), last_start, v.front()[1],
+                     v[v.size() / 2][1], v.back()[1], span);
+        for (size_t k = v.size() > 4 ? v.size() - 4 : 0; k < v.size(); ++k)
+          std::fprintf(stderr, " %d(%.2f, %.2f)", (int)v[k][2], v[k][0], v[k][1]);
+        // the last finishers
+        std::sort(v.begin(), v.end(), [](const auto& a, const auto& b2) { return a[0] + a[1] < b2[0] + b2[1]; });
+        std::fprintf(stderr, " | last to end:");
+        for (size_t k = v.size() > 3 ? v.size() - 3 : 0; k < v.size(); ++k)
+          std::fprintf(stderr, " %d(%.2f, %.2f)", (int)v[k][2], v[k][0], v[k][1]);
+        std::fprintf(stderr, "\n");
+      }
+      ck(hipMemset(d_wgprof_, 0, wg.size() * sizeof(long long)), "wgprof reset");
+    }
+#endif
     for (int q = 0; q < nprof; ++q) {
       std::fill(hprof.begin() + (size_t)kProfSlots * q, hprof.begin() + (size_t)kProfSlots * (q + 1), 0LL);
       hprof[(size_t)kProfSlots * q + 8] = -1LL;      // all ones: atomicMin target (unsigned)
