@@ -72,6 +72,19 @@ def main(d):
     print("chain gaps           %8.1f" % med(chain_gap))
     print("other kernels        %8.1f" % med(other_k))
     print("other gaps (host)    %8.1f" % med(other_gap))
+    # host gaps by position: median and mean over the steps of the idle time before each kind of non-chain launch, and of the
+    # lead before the chain (the step graph's launch)
+    from collections import defaultdict
+    by = defaultdict(list)
+    pe = None
+    for st in steps:
+        for s, e, k in st:
+            if pe is not None and (k not in chol or k == st[0][2] and s == st[0][0]):
+                by[("chain start" if k in chol else k)].append(max(0, s - pe) / 1e3)
+            pe = e
+    print("# idle time before a launch, by kind of the launch: count median mean (us)")
+    for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+        print("gap before %-16s %6d %7.2f %7.2f" % (k, len(v), med(v), sum(v) / len(v)))
     # typical sequence of one step
     st = steps[len(steps) // 2]
     print("# one step, dispatch by dispatch: kernel dur_us gap_before_us")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wall times of the BASELINE.json configurations (and a few neighbours) on one GPU, one JSON line each.
-usage: python3 tools/workloads.py [quick]"""
+usage: python3 tools/workloads.py [quick | l9]      (l9: only the two fem2d L=9 solves, 917 504 rows)"""
 import json
 import os
 import sys
@@ -37,6 +37,10 @@ def parabolic(L, p, h):
 if __name__ == "__main__":
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     solve("fem2d", 3, 1.0)                     # configs[0] (plumbing case) -- also warms the code objects
+    if len(sys.argv) > 1 and sys.argv[1] == "l9":
+        solve("fem2d", 9, 1.5)
+        solve("fem2d", 9, 1.0)
+        sys.exit(0)
     solve("fem2d", 5, 1.5)                     # configs[1]
     solve("fem2d", 7, 1.0)                     # configs[2] workload on one GPU (bench.py default)
     solve("fem2d", 7, 1.5)
