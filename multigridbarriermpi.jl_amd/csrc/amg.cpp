@@ -531,6 +531,15 @@ Amg::Level& Amg::level(int l) {
     lv.plan = shard_level_plan(lv.plan, ng_, S_, P_.K, P_.nY(), r0_, r0_ + n_);
     lv.plan.rank_mask = std::move(mask);
   }
+  if (!pcg_ && lv.plan.N > 0) {      // direct solver: every level that is visited gets factored
+    lv.chol_analysis = std::thread([this, &lv] {
+      try {
+        analyze_chol(lv);
+      } catch (...) {
+        lv.chol_analysis_error = std::current_exception();
+      }
+    });
+  }
   const double t_up = now_s();
   lv.R.upload(lv.plan.R);
   lv.B.upload(lv.plan.B);
@@ -564,16 +573,28 @@ Amg::Level& Amg::level(int l) {
 
 // the factorisation (symbolic analysis + device schedule, 230 MB of fronts at fem2d L=7) is built on first solve,
 // so that kernel-only uses of a level (time_kernels on a large mesh, f0/f1/f2 probes) do not pay for it
+// host only: elimination tree, fronts, assembly maps (MfChol::analyze)
+void Amg::analyze_chol(Level& lv) {
+  // MGB_RANK_ALIGNED=0: geometric tree + Hessian values summed over the ranks (the scheme before; kept for A/B runs)
+  static const bool aligned_on = !(std::getenv("MGB_RANK_ALIGNED") && std::atoi(std::getenv("MGB_RANK_ALIGNED")) == 0);
+  const bool ranked = aligned_on && ctx_.world > 1 && (int)lv.plan.rank_mask.size() == lv.plan.N;
+  lv.chol.analyze(lv.plan.Apat, lv.plan.coords.data(), geo_.dim, 64, ranked ? lv.plan.rank_mask.data() : nullptr, ctx_.world);
+  lv.chol_analyzed = true;
+}
+
 void Amg::ensure_chol(Level& lv) {
   if (lv.chol_built) return;
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
   static const bool vt = std::getenv("MGB_VERBOSE_SETUP") != nullptr;
   double t0 = now_s();
-  // MGB_RANK_ALIGNED=0: geometric tree + Hessian values summed over the ranks (the scheme before; kept for A/B runs)
-  static const bool aligned_on = !(std::getenv("MGB_RANK_ALIGNED") && std::atoi(std::getenv("MGB_RANK_ALIGNED")) == 0);
-  const bool ranked = aligned_on && ctx_.world > 1 && (int)lv.plan.rank_mask.size() == lv.plan.N;
-  lv.chol.analyze(lv.plan.Apat, lv.plan.coords.data(), geo_.dim, 64, ranked ? lv.plan.rank_mask.data() : nullptr, ctx_.world);
-  if (vt) std::fprintf(stderr, "[mgb setup] chol analyze                %.3f s\n", now_s() - t0);
+  if (lv.chol_analysis.joinable()) lv.chol_analysis.join();      // started by level(), beside the uploads
+  if (lv.chol_analysis_error) {
+    std::exception_ptr e = lv.chol_analysis_error;
+    lv.chol_analysis_error = nullptr;
+    std::rethrow_exception(e);
+  }
+  if (!lv.chol_analyzed) analyze_chol(lv);
+  if (vt) std::fprintf(stderr, "[mgb setup] chol analyze (rest)         %.3f s\n", now_s() - t0);
   t0 = now_s();
   lv.gchol.build(lv.chol, &ctx_);      // sharded context: split by subtrees (gpuchol.hpp)
   if (vt) std::fprintf(stderr, "[mgb setup] gpuchol build + upload      %.3f s\n", now_s() - t0);

@@ -16,6 +16,8 @@
 #include <memory>
 #include <string>
 #include <utility>
+#include <thread>
+#include <exception>
 #include <vector>
 
 #include "geometry.hpp"
@@ -359,7 +361,12 @@ class Amg {
       hipGraphExec_t exec;
     };
     std::vector<StepGraph> step_graphs;
+    // the symbolic analysis of the Cholesky factorisation (host only) runs beside the uploads and element tables of the level
+    std::thread chol_analysis;
+    std::exception_ptr chol_analysis_error;
+    bool chol_analyzed = false;
     ~Level() {
+      if (chol_analysis.joinable()) chol_analysis.join();
       for (auto& g : step_graphs) (void)hipGraphExecDestroy(g.exec);
     }
     LevelPlan plan;
@@ -391,6 +398,7 @@ class Amg {
   Level& level(int l);            // lazily built
   int level_index(const Level& lv) const;
   void ensure_chol(Level& lv);    // factorisation structures, built on first solve
+  void analyze_chol(Level& lv);   // its host-only symbolic part (runs in Level::chol_analysis beside the uploads)
   void ensure_T(Level& lv);       // the Hessian plan T on the device (lazily: only levels without an element-slab assembly, Float32, probes)
   // lower-triangle values of the level's Newton matrix from Y_ into lv.avals: element-slab assembly, or T vec(Y)
   void assemble_values(Level& lv);
