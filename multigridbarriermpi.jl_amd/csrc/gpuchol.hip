@@ -1813,7 +1813,7 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
   ck(hipFuncSetAttribute((const void*)front_step2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kStep2Lds), "attr");
 }
 
-// The whole chain is launch-bound (83 dependent launches at fem2d L=7), so it is captured once per
+// The whole chain is launch-bound (37 dependent launches at fem2d L=7), so it is captured once per
 // (values, rhs, solution) pointer triple into a hipGraph and replayed with ONE host call per Newton step; the
 // event-timed and phase-stamped variants (KernelTimer, MGB_CHOL_PROF) and MGB_CHOL_GRAPH=0 use plain launches.
 void GpuChol::factor_solve(hipStream_t st, double* d_vals, const double* d_b, double* d_x, KernelTimer* tm, bool flag_armed,
