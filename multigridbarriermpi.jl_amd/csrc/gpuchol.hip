@@ -524,7 +524,7 @@ __device__ __forceinline__ void trsm_block64(double* AT, int TP, const double* L
 }
 
 // the same for the two panel blocks of an off-diagonal tile at once (rows 16 w .. of both, side by side in every wave)
-template <bool EXIT = false>
+template <bool EXIT = false, bool PACKED = false>
 __device__ __forceinline__ void trsm_block64_pair(double* ATI, double* ATJ, int TP, const double* Lq, int kw = PB) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = 16 * w + (lane >> 2), c4 = lane & 3;
   double f[2][PB / 4];
@@ -533,7 +533,7 @@ __device__ __forceinline__ void trsm_block64_pair(double* ATI, double* ATJ, int 
     f[0][k] = ATI[(c4 + 4 * k) * TP + r];
     f[1][k] = ATJ[(c4 + 4 * k) * TP + r];
   }
-  trsm_quad_n<2, EXIT, false>(f, Lq, c4, kw);
+  trsm_quad_n<2, EXIT, PACKED>(f, Lq, c4, kw);
 #pragma unroll
   for (int k = 0; k < PB / 4; ++k) {
     ATI[(c4 + 4 * k) * TP + r] = f[0][k];
@@ -950,19 +950,24 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // the pivot block; the tj == 0 tiles the mirrored rows of L.
 // NARROW: launches whose fronts have at most 8 pivots skip the identity padding in the factor, the substitution,
 // the update and the gather of the panel columns.
-template <bool NARROW>
-__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void front_single_kernel(
+// DENSE (launches with more tiles than two per CU can hold at once: fem2d L >= 8, where these launches run 8-16 rounds of
+// workgroups and are bound by how many of them a CU holds): the factor stays in its packed row-major form and the
+// substitutions read it there (as front_leaf does) instead of from a second copy in quad order: 51 instead of 63 KB of
+// LDS, three workgroups per CU instead of two.  Same operations in the same order: bitwise the same result.
+template <bool NARROW, bool DENSE>
+__device__ __forceinline__ void front_single_body(
     const SingleTile* __restrict__ tiles, const int* __restrict__ pinv,
     const int* __restrict__ asm_src, const int* __restrict__ asm_pos, const double* __restrict__ vals,
     const int* __restrict__ perm, const double* __restrict__ b, const double* __restrict__ fronts_ro, double* fronts,
     double* linv, int* fail, long long* prof) {
   constexpr int TP = TS + 8;      // row stride of the staged panel blocks (as in front_step)
-  __shared__ __attribute__((aligned(32))) double sh[2 * PB * TP + PB * PB + 2 * PB * LP];
+  constexpr int kFactorLds = DENSE ? PB * LP + PB * (PB + 1) / 2 : PB * PB + 2 * PB * LP;      // D | Lo (packed)  or  Lc | D | Lo
+  __shared__ __attribute__((aligned(32))) double sh[2 * PB * TP + kFactorLds];
   __shared__ int rowI[2][TS], rowJ[2][TS], piv[2][PB];
   double* ATI = sh;
   double* ATJ = sh + PB * TP;
-  double* Lc = sh + 2 * PB * TP;
-  double* D = Lc + PB * PB;
+  double* Lc = sh + 2 * PB * TP;                       // (not DENSE) the factor in quad order
+  double* D = DENSE ? sh + 2 * PB * TP : Lc + PB * PB;
   double* Lo = D + PB * LP;
   STAMP(0);
   const SingleTile t = tiles[blockIdx.x];      // carries everything of the node and its children: no dependent loads
@@ -1074,12 +1079,15 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
   if (prm >= 0) ATI[tid * TP + nf - r0] += bval;      // ns <= 32 <= TB: one entry per thread
   __syncthreads();
-  factor_diag_block<NARROW>(D, kw, Lo, (t.ti == 0 && t.tj == 0) ? linv + t.loff : nullptr, fail, nullptr);
-  for (int idx = tid; idx < PB * PB; idx += TB) Lc[lq_index(idx % PB, idx / PB)] = Lo[(idx % PB) * LP + idx / PB];     // L[m][j], quad order
-  __syncthreads();
+  factor_diag_block<NARROW, DENSE>(D, kw, Lo, (t.ti == 0 && t.tj == 0) ? linv + t.loff : nullptr, fail, nullptr);
+  if (!DENSE) {
+    for (int idx = tid; idx < PB * PB; idx += TB) Lc[lq_index(idx % PB, idx / PB)] = Lo[(idx % PB) * LP + idx / PB];     // L[m][j], quad order
+    __syncthreads();
+  }
   STAMP(2);
-  if (diag) trsm_block64<NARROW>(ATI, TP, Lc, kw);      // all four waves, four lanes per row (see front_step)
-  else trsm_block64_pair<NARROW>(ATI, ATJ, TP, Lc, kw);
+  const double* Lf = DENSE ? Lo : Lc;
+  if (diag) trsm_block64<NARROW, DENSE>(ATI, TP, Lf, kw);      // all four waves, four lanes per row (see front_step)
+  else trsm_block64_pair<NARROW, DENSE>(ATI, ATJ, TP, Lf, kw);
   __syncthreads();
   if (t.tj == min((int)t.ti, max(1, (nf - k1 + TS - 1) / TS) - 1)) {      // the row block's last (diagonal) tile, see front_step
     for (int idx = tid; idx < TS * PB; idx += TB) {
@@ -1110,6 +1118,22 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       if (i <= nf && j < nf && i >= j) F[(long long)ld * j + i] = acc[bj][reg];
     }
   STAMP(7);
+}
+
+template <bool NARROW>
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void front_single_kernel(
+    const SingleTile* __restrict__ tiles, const int* __restrict__ pinv, const int* __restrict__ asm_src,
+    const int* __restrict__ asm_pos, const double* __restrict__ vals, const int* __restrict__ perm, const double* __restrict__ b,
+    const double* __restrict__ fronts_ro, double* fronts, double* linv, int* fail, long long* prof) {
+  front_single_body<NARROW, false>(tiles, pinv, asm_src, asm_pos, vals, perm, b, fronts_ro, fronts, linv, fail, prof);
+}
+
+template <bool NARROW>
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(3, 3))) void front_single_dense_kernel(
+    const SingleTile* __restrict__ tiles, const int* __restrict__ pinv, const int* __restrict__ asm_src,
+    const int* __restrict__ asm_pos, const double* __restrict__ vals, const int* __restrict__ perm, const double* __restrict__ b,
+    const double* __restrict__ fronts_ro, double* fronts, double* linv, int* fail, long long* prof) {
+  front_single_body<NARROW, true>(tiles, pinv, asm_src, asm_pos, vals, perm, b, fronts_ro, fronts, linv, fail, prof);
 }
 
 // Leaf heights (no children) whose fronts fit LDS and whose trailing matrix after the first panel is one 64x64
@@ -1870,7 +1894,14 @@ void GpuChol::enqueue_forward(hipStream_t st, const std::vector<HeightPlan>& pla
     }
     if (hp.single) {
       if (tm) tm->begin(st, KC_CHOL_SINGLE, hp.start_bytes + hp.step_bytes[0]);
-      hipLaunchKernelGGL(hp.narrow ? front_single_kernel<true> : front_single_kernel<false>, dim3(hp.single_tiles.cnt), dim3(TB), 0, st, d_singles_ + hp.single_tiles.ofs, d_pinv_,
+      static const int dense_tiles = [] {      // MGB_CHOL_DENSE_TILES: launches above this many tiles use the three-per-CU variant
+        const char* e = std::getenv("MGB_CHOL_DENSE_TILES");
+        return e ? std::atoi(e) : 1024;
+      }();
+      const bool dense = hp.single_tiles.cnt > dense_tiles;
+      hipLaunchKernelGGL(dense ? (hp.narrow ? front_single_dense_kernel<true> : front_single_dense_kernel<false>)
+                               : (hp.narrow ? front_single_kernel<true> : front_single_kernel<false>),
+                         dim3(hp.single_tiles.cnt), dim3(TB), 0, st, d_singles_ + hp.single_tiles.ofs, d_pinv_,
                          d_asm_src_, d_asm_pos_, d_vals, d_perm_, d_b, d_fronts_, d_fronts_, d_linv_, d_fail_,
                          d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr);
       if (tm) tm->end(st);
