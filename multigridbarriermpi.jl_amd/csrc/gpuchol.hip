@@ -704,8 +704,23 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 3))) void
 // and factor the corner that becomes the pivot block of the NEXT launch.
 // LDS (dynamic, 115 KB): L11 and L22 in quad order, L21, the corner, the factor scratch, two 64 x 64 panel blocks.
 constexpr int kStep2Lds = (2 * PB * PB + 3 * PB * LP + 2 * 2 * PB * (TS + 8)) * (int)sizeof(double);
+// The same two panels as TWO launches, for the heights whose tile count is beyond what one workgroup per CU handles in a
+// round (fem2d L >= 8, the upper heights of fem3d): there the one-panel kernel was used, which re-reads and re-writes the
+// whole trailing matrix per 32 columns.
+//   MODE 1, "panel": one workgroup per block of trailing rows.  Everything of the fused kernel up to the solved panel blocks
+//     X = [X1 X2] of its rows, which go to the mirrored rows of L AND back into the panel's own (column-major) place, dead
+//     from here on in the forward sweep.  The first 32 trailing rows belong to the front's pivot workgroup (first in the
+//     launch: it publishes L21 / L22 and factors the next pivot block from those rows, the chain's critical path), the
+//     64-row blocks start behind them -- nobody reads panel rows another workgroup overwrites.  78 KB of LDS (no second
+//     panel block): two per CU.
+//   MODE 2, "update": the fused kernel's tiles with everything between staging and the rank-64 update removed -- the staged
+//     panel blocks ARE the solved ones.  74 KB of LDS: two per CU.
+// Operation order per entry is that of the fused kernel (and of two rank-32 steps): bitwise the same factor.
+constexpr int kPanel2Lds = (2 * PB * PB + 3 * PB * LP + 2 * PB * (TS + 8)) * (int)sizeof(double);
+constexpr int kUpdate2Lds = (2 * 2 * PB * (TS + 8)) * (int)sizeof(double);
 
-__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void front_step2_kernel(
+template <int MODE>
+__device__ __forceinline__ void front_step2_body(
     const StepTile* __restrict__ tiles, int p, int npiv, double* fronts, const double* __restrict__ linv_ro, double* linv, int* fail,
     long long* prof) {
   constexpr int TP = TS + 8;
@@ -715,25 +730,28 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   double* P = Lc2 + PB * PB;            // L21: P[r * LP + m]
   double* D = P + PB * LP;              // corner A22 - L21 L21' (pivot workgroups: later the next launch's pivot block)
   double* Lo = D + PB * LP;             // factor scratch / L22 row-major
-  double* ATI = Lo + PB * LP;           // AT[q * TP + r]: q < 32 first panel, q >= 32 second panel
-  double* ATJ = ATI + 2 * PB * TP;
+  double* ATI = MODE == 2 ? sh2 : Lo + PB * LP;      // AT[q * TP + r]: q < 32 first panel, q >= 32 second panel
+  double* ATJ = ATI + 2 * PB * TP;                   // (MODE 1: never touched, not allocated)
   STAMP(0);
   const StepTile t = tiles[blockIdx.x];
-  const bool is_piv = (int)blockIdx.x < npiv;      // workgroup-uniform
+  const bool is_piv = MODE != 2 && (int)blockIdx.x < npiv;      // workgroup-uniform
   const int nf = t.nf, ld = nf + 1, k0 = p * PB, k1 = min(t.ns, k0 + PB), k2 = min(t.ns, k1 + PB), kw = k1 - k0, kw2 = k2 - k1;
   const int kw3 = min(PB, t.ns - k2);              // pivot workgroups: width of the next pivot block
   double* F = fronts + t.off;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
-  const int r0 = is_piv ? k2 : k2 + TS * t.ti, c0 = is_piv ? k2 : k2 + TS * t.tj;
+  const int roff = MODE == 1 ? PB : 0;             // panel launch: the 64-row blocks start behind the pivot workgroup's 32 rows
+  const int r0 = is_piv ? k2 : k2 + roff + TS * t.ti, c0 = is_piv ? k2 : k2 + TS * t.tj;
   const bool diag = is_piv || (t.ti == t.tj);
-  const int rows_here = is_piv ? kw3 : TS;         // pivot workgroups stage only the rows of the next pivot block
+  // pivot workgroups stage only the rows of the next pivot block (panel launch: all of their 32 rows)
+  const int rows_here = is_piv ? (MODE == 1 ? PB : kw3) : TS;
   typedef double v4f64 __attribute__((ext_vector_type(4)));
-  for (int idx = tid; idx < PB * PB; idx += TB) Lc1[lq_index(idx % PB, idx / PB)] = linv_ro[t.loff + PB * PB + idx];
+  if (MODE != 2)
+    for (int idx = tid; idx < PB * PB; idx += TB) Lc1[lq_index(idx % PB, idx / PB)] = linv_ro[t.loff + PB * PB + idx];
   // second pivot block: its 32 rows of the first panel (waves 0, 1: four lanes per row) and its lower triangle as three
   // 16x16 blocks in the MFMA result layout (waves 0..2) -- see pivot_path
   const int bi = (w + 1) >> 1, bj3 = w >> 1, ci = 16 * bi + li;
   v4f64 accD = v4f64{0.0, 0.0, 0.0, 0.0};
-  if (w < 3) {
+  if (MODE != 2 && w < 3) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int j = 16 * bj3 + lk + 4 * reg;
@@ -742,7 +760,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
   const int pr = 16 * w + (lane >> 2), c4 = lane & 3;
   double f[PB / 4];
-  if (w < 2) {
+  if (MODE != 2 && w < 2) {
 #pragma unroll
     for (int k = 0; k < PB / 4; ++k) {
       const int m = c4 + 4 * k;
@@ -779,7 +797,8 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         accN[reg] = (j <= ci && ci < kw3) ? F[(long long)ld * (k2 + j) + k2 + ci] : 0.0;
       }
     }
-  } else {
+  }
+  if (MODE != 1 && !is_piv) {
 #pragma unroll
     for (int bj = 0; bj < 4; ++bj)
 #pragma unroll
@@ -795,6 +814,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
   __syncthreads();
   STAMP(1);
+  if (MODE != 2) {      // (the update launch's staged blocks are the solved ones)
   if (w < 2) {      // L21 = A21 L11^-T
     trsm_quad(f, Lc1, c4);
 #pragma unroll
@@ -878,7 +898,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   __syncthreads();
   STAMP(3);
   for (int idx = tid; idx < PB * PB; idx += TB) Lc2[lq_index(idx % PB, idx / PB)] = Lo[(idx % PB) * LP + idx / PB];
-  if (!is_piv && t.ti == 0 && t.tj == 0 && kw2 > 0) {      // this front's publisher of the second pivot block and of the rows of L21 (if it has a second panel)
+  if ((MODE == 1 ? is_piv : (!is_piv && t.ti == 0 && t.tj == 0)) && kw2 > 0) {      // this front's publisher of the second pivot block and of the rows of L21 (if it has a second panel)
     double* lp = linv + t.loff + 2 * PB * PB;
     for (int idx = tid; idx < PB * PB; idx += TB) {
       const int r = idx / PB, m = idx % PB;
@@ -892,6 +912,23 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   else trsm_block64_pair(ATI + PB * TP, ATJ + PB * TP, TP, Lc2);
   __syncthreads();
   STAMP(4);
+  if (MODE == 1) {
+    // the solved rows go to the mirrored half (the backward sweep's rows of L) and back into the panel itself, where the
+    // update launch stages them from like the fused kernel stages the unsolved ones
+    for (int idx = tid; idx < TS * 2 * PB; idx += TB) {
+      const int r = idx / (2 * PB), q = idx % (2 * PB);
+      const int col = (q < PB) ? k0 + q : k1 + q - PB;
+      const bool okc = (q < PB) ? (q < kw) : (q - PB < kw2);
+      if (r < rows_here && r0 + r <= nf && okc) F[(long long)ld * (r0 + r) + col] = ATI[q * TP + r];
+    }
+    for (int idx = tid; idx < TS * 2 * PB; idx += TB) {
+      const int r = idx % TS, q = idx / TS;
+      const int col = (q < PB) ? k0 + q : k1 + q - PB;
+      const bool okc = (q < PB) ? (q < kw) : (q - PB < kw2);
+      if (r < rows_here && r0 + r <= nf && okc) F[(long long)ld * col + r0 + r] = ATI[q * TP + r];
+    }
+    if (!(is_piv && k2 < t.ns)) return;      // workgroup-uniform: only a pivot workgroup with a next pivot block goes on
+  }
   if (is_piv) {
     // next pivot block: corner - [X1 X2] [X1 X2]' over its 32 rows, then the factor the NEXT launch starts from
     if (w < 3) {
@@ -908,7 +945,8 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     STAMP(7);
     return;
   }
-  if (t.tj == min((int)t.ti, max(1, (nf - k2 + TS - 1) / TS) - 1)) {      // finished rows of L (both panels) go to the mirrored half: the row block's last (diagonal) tile, see front_step
+  }      // MODE != 2
+  if (MODE == 0 && t.tj == min((int)t.ti, max(1, (nf - k2 + TS - 1) / TS) - 1)) {      // finished rows of L (both panels) go to the mirrored half: the row block's last (diagonal) tile, see front_step
     for (int idx = tid; idx < TS * 2 * PB; idx += TB) {
       const int r = idx / (2 * PB), q = idx % (2 * PB);
       const int col = (q < PB) ? k0 + q : k1 + q - PB;
@@ -939,6 +977,24 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       if (i <= nf && j < nf && i >= j && !(i < kc && j < kc)) F[(long long)ld * j + i] = acc[bj][reg];
     }
   STAMP(7);
+}
+
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(1, 1))) void front_step2_kernel(
+    const StepTile* __restrict__ tiles, int p, int npiv, double* fronts, const double* __restrict__ linv_ro, double* linv, int* fail,
+    long long* prof) {
+  front_step2_body<0>(tiles, p, npiv, fronts, linv_ro, linv, fail, prof);
+}
+
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void front_panel2_kernel(
+    const StepTile* __restrict__ tiles, int p, int npiv, double* fronts, const double* __restrict__ linv_ro, double* linv, int* fail,
+    long long* prof) {
+  front_step2_body<1>(tiles, p, npiv, fronts, linv_ro, linv, fail, prof);
+}
+
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void front_update2_kernel(
+    const StepTile* __restrict__ tiles, int p, int npiv, double* fronts, const double* __restrict__ linv_ro, double* linv, int* fail,
+    long long* prof) {
+  front_step2_body<2>(tiles, p, npiv, fronts, linv_ro, linv, fail, prof);
 }
 
 // Heights whose fronts all have a single panel (ns <= 32; at fem2d L=7 five of the eleven heights): front_start and
@@ -1556,6 +1612,10 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
     return !(e && e[0] == '0');
   }();
   start_pivot_ = start_pivot_ok;
+  static const bool wide_ok = [] {      // MGB_CHOL_WIDE=0: one panel per launch beyond the fused kernel's tile count (the scheme before)
+    const char* e = std::getenv("MGB_CHOL_WIDE");
+    return !(e && e[0] == '0');
+  }();
   static const int step2_max_tiles = [] {
     const char* e = std::getenv("MGB_CHOL_STEP2_TILES");
     return e ? std::atoi(e) : 224;
@@ -1645,6 +1705,80 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
         for (int ti = 0; ti < Tr; ++ti) ntile2 += std::min(ti, Tc - 1) + 1;
       }
       const bool pair = step2_ok && !hp.single && p + 1 < npanel && ntile2 <= step2_max_tiles;
+      // beyond that tile count: the same two panels as a panel launch (one workgroup per 64-row block, row block 0 also
+      // factors the next pivot block) and an update launch (the tiles, rank-64, nothing else) -- see front_step2_body
+      const bool wide = wide_ok && step2_ok && !hp.single && p + 1 < npanel && !pair;
+      if (wide) {
+        double pbytes = 0, ubytes = 0;
+        for (int t : mine) {
+          const GNode& g = nodes[t];
+          if (g.ns <= p * PB) continue;
+          const int k2 = std::min(g.ns, (p + 2) * PB), Tr = (g.nf + 1 - k2 + TS - 1) / TS;
+          StepTile st{};
+          st.off = g.off;
+          st.loff = g.loff + (long long)p * 2 * PB * PB;
+          st.nf = g.nf;
+          st.ns = g.ns;
+          st.pad = t;
+          (void)Tr;
+          tiles.push_back(st);      // the front's pivot workgroup: trailing rows k2 .. k2 + 31
+          npiv++;
+          const double tr = g.nf + 1 - k2;
+          pbytes += tr * (k2 - p * PB) * 32.0;      // panel read, mirrored + in-place write
+        }
+        for (int t : mine) {
+          const GNode& g = nodes[t];
+          if (g.ns <= p * PB) continue;
+          const int k2 = std::min(g.ns, (p + 2) * PB), Trw = std::max(0, (g.nf + 1 - k2 - PB + TS - 1) / TS);
+          StepTile st{};
+          st.off = g.off;
+          st.loff = g.loff + (long long)p * 2 * PB * PB;
+          st.nf = g.nf;
+          st.ns = g.ns;
+          st.pad = t;
+          for (int ti = 0; ti < Trw; ++ti) {
+            st.ti = st.tj = (short)ti;
+            tiles.push_back(st);
+          }
+        }
+        rt.cnt = (int)tiles.size() - rt.ofs;
+        hp.step_npiv.push_back(npiv);
+        hp.step.push_back(rt);
+        hp.step_bytes.push_back(pbytes);
+        hp.step_p.push_back(p);
+        hp.step_pair.push_back(2);
+        launches_++;
+        Range ru{(int)tiles.size(), 0};
+        for (int t : mine) {
+          const GNode& g = nodes[t];
+          if (g.ns <= p * PB) continue;
+          const int k2 = std::min(g.ns, (p + 2) * PB), Tr = (g.nf + 1 - k2 + TS - 1) / TS, Tc = std::max(1, (g.nf - k2 + TS - 1) / TS);
+          if (Tr > 30000) throw ArgError("gpuchol: front too large for tile index");
+          StepTile st{};
+          st.off = g.off;
+          st.loff = g.loff + (long long)p * 2 * PB * PB;
+          st.nf = g.nf;
+          st.ns = g.ns;
+          st.pad = t;
+          for (int ti = 0; ti < Tr; ++ti)
+            for (int tj = 0; tj <= std::min(ti, Tc - 1); ++tj) {
+              st.ti = (short)ti;
+              st.tj = (short)tj;
+              tiles.push_back(st);
+            }
+          const double tr = g.nf + 1 - k2;
+          ubytes += tr * (k2 - p * PB) * 8.0 + 0.5 * tr * tr * 16.0;      // solved panel read, trailing read + write
+        }
+        ru.cnt = (int)tiles.size() - ru.ofs;
+        hp.step_npiv.push_back(0);
+        hp.step.push_back(ru);
+        hp.step_bytes.push_back(ubytes);
+        hp.step_p.push_back(p);
+        hp.step_pair.push_back(3);
+        launches_++;
+        ++p;
+        continue;
+      }
       const int np = pair ? 2 : 1;
       for (int pass = 0; pass < 2; ++pass)
         for (int t : mine) {
@@ -1835,6 +1969,8 @@ void GpuChol::build(const MfChol& sym, Ctx* ctx) {
   ck(hipFuncSetAttribute((const void*)backward_rect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "attr");
   ck(hipFuncSetAttribute((const void*)front_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024), "attr");
   ck(hipFuncSetAttribute((const void*)front_step2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kStep2Lds), "attr");
+  ck(hipFuncSetAttribute((const void*)front_panel2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPanel2Lds), "attr");
+  ck(hipFuncSetAttribute((const void*)front_update2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kUpdate2Lds), "attr");
 }
 
 // The whole chain is launch-bound (37 dependent launches at fem2d L=7), so it is captured once per
@@ -1914,7 +2050,13 @@ void GpuChol::enqueue_forward(hipStream_t st, const std::vector<HeightPlan>& pla
     if (tm) tm->end(st);
     for (size_t q = 0; q < hp.step.size(); ++q) {
       if (tm) tm->begin(st, KC_CHOL_STEP, hp.step_bytes[q]);
-      if (hp.step_pair[q])
+      if (hp.step_pair[q] == 2)
+        hipLaunchKernelGGL(front_panel2_kernel, dim3(hp.step[q].cnt), dim3(TB), kPanel2Lds, st, d_tiles_ + hp.step[q].ofs, hp.step_p[q],
+                           hp.step_npiv[q], d_fronts_, d_linv_, d_linv_, d_fail_, d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr);
+      else if (hp.step_pair[q] == 3)
+        hipLaunchKernelGGL(front_update2_kernel, dim3(hp.step[q].cnt), dim3(TB), kUpdate2Lds, st, d_tiles_ + hp.step[q].ofs, hp.step_p[q],
+                           0, d_fronts_, d_linv_, d_linv_, d_fail_, d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr);
+      else if (hp.step_pair[q])
         hipLaunchKernelGGL(front_step2_kernel, dim3(hp.step[q].cnt), dim3(TB), kStep2Lds, st, d_tiles_ + hp.step[q].ofs, hp.step_p[q],
                            hp.step_npiv[q], d_fronts_, d_linv_, d_linv_, d_fail_, d_prof_ ? d_prof_ + kProfSlots * (nprof++) : nullptr);
       else

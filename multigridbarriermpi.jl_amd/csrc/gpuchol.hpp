@@ -187,7 +187,7 @@ class GpuChol {
     Range single_tiles{0, 0};
     std::vector<int> step_npiv;   // leading pivot workgroups of every step launch
     std::vector<int> step_p;      // first panel of the launch
-    std::vector<char> step_pair;  // 1: two panels (front_step2)
+    std::vector<char> step_pair;  // 0: one panel (front_step), 1: two panels fused (front_step2), 2 / 3: two panels as a panel launch and an update launch
     std::vector<double> step_bytes;
     double start_bytes, rect_bytes, tri_bytes;
     int max_nf;

@@ -42,7 +42,7 @@ def report(d):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
                              int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0), int(r.get("Workgroup_Size_X", 1) or 1)))
     rows.sort()
-    names = ("front_leaf_kernel", "front_single_kernel", "front_start_kernel", "front_step_kernel", "front_step2_kernel", "backward_rect_kernel", "backward_kernel")
+    names = ("front_leaf_kernel", "front_single_dense_kernel", "front_single_kernel", "front_start_kernel", "front_step_kernel", "front_step2_kernel", "front_panel2_kernel", "front_update2_kernel", "backward_rect_kernel", "backward_kernel")
 
     def short(s):
         for nm in names:
@@ -53,7 +53,7 @@ def report(d):
     # every factor+solve chain: from a factorisation launch that does not follow another one to the last backward_kernel
     # before the next chain; chains with the launch count of the last one are kept (the first one also builds the graph)
     ks = [short(r[2]) for r in rows]
-    fact = ("front_leaf_kernel", "front_start_kernel", "front_single_kernel", "front_step_kernel", "front_step2_kernel")
+    fact = ("front_leaf_kernel", "front_start_kernel", "front_single_kernel", "front_single_dense_kernel", "front_step_kernel", "front_step2_kernel", "front_panel2_kernel", "front_update2_kernel")
     starts = [i for i, k in enumerate(ks) if k in fact[:2] and (i == 0 or ks[i - 1] not in fact)]
     chains = []
     for a, b in zip(starts, starts[1:] + [len(rows)]):

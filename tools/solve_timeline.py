@@ -14,7 +14,7 @@ import sys
 
 
 def short(name):
-    for k in ("front_leaf", "front_single", "front_start", "front_step", "backward_rect", "backward_kernel", "trial_f0", "barrier_f0",
+    for k in ("front_leaf", "front_single", "front_start", "front_step", "front_panel2", "front_update2", "backward_rect", "backward_kernel", "trial_f0", "barrier_f0",
               "barrier_f1", "barrier_f2", "spmv_kernel", "elop_assemble", "gather_sum", "elop_apply", "dof_gather", "csr_apply", "dot_kernel", "sum_kernel", "final_sum", "waxpby", "copyBuffer", "fillBuffer",
               "front_top"):
         if k in name:
@@ -29,7 +29,7 @@ def main(d):
             for r in csv.DictReader(fh):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     rows.sort()
-    chol = {"front_leaf", "front_single", "front_start", "front_step", "backward_rect", "backward_kernel", "front_top"}
+    chol = {"front_leaf", "front_single", "front_start", "front_step", "front_panel2", "front_update2", "backward_rect", "backward_kernel", "front_top"}
     # Newton steps: maximal runs [chain][other kernels]
     steps, cur, in_chain = [], [], False
     for s, e, k in rows:
