@@ -1006,8 +1006,8 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // the pivot block; the tj == 0 tiles the mirrored rows of L.
 // NARROW: launches whose fronts have at most 8 pivots skip the identity padding in the factor, the substitution,
 // the update and the gather of the panel columns.
-// DENSE (launches with more tiles than two per CU can hold at once: fem2d L >= 8, where these launches run 8-16 rounds of
-// workgroups and are bound by how many of them a CU holds): the factor stays in its packed row-major form and the
+// DENSE (launches with more tiles than two per CU can hold at once, 512: fem2d L >= 8, where these launches run up to 16 rounds
+// of workgroups and are bound by how many of them a CU holds): the factor stays in its packed row-major form and the
 // substitutions read it there (as front_leaf does) instead of from a second copy in quad order: 51 instead of 63 KB of
 // LDS, three workgroups per CU instead of two.  Same operations in the same order: bitwise the same result.
 template <bool NARROW, bool DENSE>
@@ -2032,7 +2032,7 @@ void GpuChol::enqueue_forward(hipStream_t st, const std::vector<HeightPlan>& pla
       if (tm) tm->begin(st, KC_CHOL_SINGLE, hp.start_bytes + hp.step_bytes[0]);
       static const int dense_tiles = [] {      // MGB_CHOL_DENSE_TILES: launches above this many tiles use the three-per-CU variant
         const char* e = std::getenv("MGB_CHOL_DENSE_TILES");
-        return e ? std::atoi(e) : 1024;
+        return e ? std::atoi(e) : 512;      // what two tiles per CU hold at once
       }();
       const bool dense = hp.single_tiles.cnt > dense_tiles;
       hipLaunchKernelGGL(dense ? (hp.narrow ? front_single_dense_kernel<true> : front_single_dense_kernel<false>)
