@@ -783,13 +783,15 @@ def test_end_point_does_not_depend_on_summation_order(M):
                        timeout=600)
     assert r.returncode == 0, r.stderr[-500:]
     rows = [ln for ln in r.stdout.splitlines() if "|z - z_default|" in ln]
-    assert len(rows) == 6, r.stdout
+    assert len(rows) == 8, r.stdout
     for ln in rows:
         assert "t_final 1e+08" in ln, ln
         assert float(ln.rsplit("=", 1)[1]) < ZTOL, ln
-    # two panels per launch (front_step2) against one: the same factorisation bit for bit, hence the same solve
-    one = [ln for ln in rows if ln.startswith("one_panel_steps")]
-    assert len(one) == 1 and float(one[0].rsplit("=", 1)[1]) == 0.0, one
+    # two panels per launch (front_step2) against one, the two panels as a panel + an update launch, three single-panel tiles
+    # per CU: the same factorisation bit for bit, hence the same solve
+    for name in ("one_panel_steps", "panel_update_pairs", "dense_single_tiles"):
+        one = [ln for ln in rows if ln.startswith(name)]
+        assert len(one) == 1 and float(one[0].rsplit("=", 1)[1]) == 0.0, one
 
 
 @pytest.mark.parametrize("kind,L,p", [("fem1d", 4, 2.0), ("fem2d", 3, 1.5)])

@@ -27,7 +27,10 @@ if __name__ == "__main__":
     p = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
     variants = [("default", {}), ("bwd_split_96", {"MGB_BWD_SPLIT_NF": "96"}), ("bwd_split_never", {"MGB_BWD_SPLIT_NF": "100000"}),
                 ("leaf_96", {"MGB_LEAF": "96"}), ("no_fused_trial", {"MGB_FUSED_TRIAL_ROWS": "0"}),
-                ("one_panel_steps", {"MGB_CHOL_STEP2": "0"})]      # front_step2 is bitwise two front_step launches: distance exactly 0
+                ("one_panel_steps", {"MGB_CHOL_STEP2": "0"}),      # front_step2 is bitwise two front_step launches: distance exactly 0
+                # ... and so are the two panels as a panel + an update launch (forced for every multi-panel height) and the
+                # three-per-CU single-panel tiles (forced for every single-panel launch)
+                ("panel_update_pairs", {"MGB_CHOL_STEP2_TILES": "0"}), ("dense_single_tiles", {"MGB_CHOL_DENSE_TILES": "0"})]
     zs = {}
     print("# fem2d L=%d p=%g: one solve per variant (fresh process each)" % (L, p))
     for name, env in variants:
