@@ -531,7 +531,9 @@ Amg::Level& Amg::level(int l) {
     lv.plan = shard_level_plan(lv.plan, ng_, S_, P_.K, P_.nY(), r0_, r0_ + n_);
     lv.plan.rank_mask = std::move(mask);
   }
-  if (!pcg_ && lv.plan.N > 0) {      // direct solver: every level that is visited gets factored
+  if (!pcg_ && lv.plan.N > 0 && !lv.chol_analyzed) {      // direct solver: every level that is visited gets factored
+    if (lv.chol_analysis.joinable()) lv.chol_analysis.join();      // (a retry after a failed build of this level)
+    lv.chol_analysis_error = nullptr;
     lv.chol_analysis = std::thread([this, &lv] {
       try {
         analyze_chol(lv);
