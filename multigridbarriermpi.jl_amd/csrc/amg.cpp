@@ -519,6 +519,9 @@ int Amg::level_index(const Level& lv) const {
 Amg::Level& Amg::level(int l) {
   Level& lv = *levels_.at(l);
   if (lv.built) return lv;
+  if (lv.chol_analysis.joinable()) lv.chol_analysis.join();      // a retry after a failed build: that analysis read the old plan
+  lv.chol_analyzed = false;
+  lv.chol_analysis_error = nullptr;
   hip_check(hipSetDevice(ctx_.device), "hipSetDevice");
   // single GPU with element-local operators: the Newton matrix is assembled element by element (DevElAsmOwned) and the plan T is
   // only built if something asks for it (ensure_T); sharded jobs and geometries without element blocks keep T
@@ -531,9 +534,7 @@ Amg::Level& Amg::level(int l) {
     lv.plan = shard_level_plan(lv.plan, ng_, S_, P_.K, P_.nY(), r0_, r0_ + n_);
     lv.plan.rank_mask = std::move(mask);
   }
-  if (!pcg_ && lv.plan.N > 0 && !lv.chol_analyzed) {      // direct solver: every level that is visited gets factored
-    if (lv.chol_analysis.joinable()) lv.chol_analysis.join();      // (a retry after a failed build of this level)
-    lv.chol_analysis_error = nullptr;
+  if (!pcg_ && lv.plan.N > 0) {      // direct solver: every level that is visited gets factored
     lv.chol_analysis = std::thread([this, &lv] {
       try {
         analyze_chol(lv);
