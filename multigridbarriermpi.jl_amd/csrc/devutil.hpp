@@ -50,6 +50,28 @@ __device__ inline double block_sum(double v, double* lds) {
   return r;
 }
 
+// N block sums at once: one pair of barriers instead of N (per value the additions and their order are those of block_sum);
+// results valid in thread 0
+template <int N>
+__device__ inline void block_sum_n(const double (&v)[N], double (&out)[N]) {
+  __shared__ double red[N][kBlock / 64];
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 0; o < N; ++o) {
+    const double w = wave_sum(v[o]);
+    if ((threadIdx.x & 63) == 0) red[o][wave] = w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int o = 0; o < N; ++o) {
+    double r = 0.0;
+    if (threadIdx.x == 0)
+      for (int i = 0; i < kBlock / 64; ++i) r += red[o][i];
+    out[o] = r;
+  }
+  __syncthreads();
+}
+
 // Grid-wide sum of per-block partial results WITHOUT a second launch: thread 0 of every block publishes its `NOUT` values
 // (write-through sc1 stores, drained), then takes a ticket; the block whose ticket is the last one reads all partials
 // back (sc1 loads, bypassing its L1) and sums them in a FIXED order -- thread-strided, then the block tree -- so the
@@ -87,15 +109,33 @@ __device__ inline void grid_finish(const double (&r)[NOUT] /* valid in thread 0 
   }
   __syncthreads();
   if (!is_last) return;      // workgroup-uniform
+  // all NOUT values of a block are read in one go (the loads bypass this XCD's L2: one memory round trip per batch; a loop
+  // over the outputs paid NOUT of them one after the other, 6 in the fused objective kernel); per output the additions keep
+  // their order (thread-strided, then the block tree)
+  double acc[NOUT];
 #pragma unroll
-  for (int o = 0; o < NOUT; ++o) {
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock)
-      acc += __hip_atomic_load(&partials[(size_t)i * NOUT + o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double tot = block_sum(acc, lds);
-    if (threadIdx.x == 0) {
-      if (out_dev) out_dev[o] = tot;
-      if (out_host) __hip_atomic_store(&out_host[o], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  for (int o = 0; o < NOUT; ++o) acc[o] = 0.0;
+  for (int i0 = threadIdx.x; i0 < (int)gridDim.x; i0 += 4 * kBlock) {      // four blocks' values per batch (index clamped, sum selected)
+    double v[4][NOUT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + u * kBlock, (int)gridDim.x - 1);
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) v[u][o] = __hip_atomic_load(&partials[(size_t)i * NOUT + o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) acc[o] = (i0 + u * kBlock < (int)gridDim.x) ? acc[o] + v[u][o] : acc[o];
+  }
+  double tot[NOUT];
+  block_sum_n<NOUT>(acc, tot);
+  (void)lds;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      if (out_dev) out_dev[o] = tot[o];
+      if (out_host) __hip_atomic_store(&out_host[o], tot[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   if (sig.seq_host && threadIdx.x == 0) {      // results first (drained), then the sequence number the host polls
@@ -130,14 +170,24 @@ __device__ inline void grid_finish_fn(const double (&r)[NOUT] /* valid in thread
   }
   __syncthreads();
   if (!is_last_fn) return;      // workgroup-uniform
-  double tot[NOUT];
+  double tot[NOUT], acc[NOUT];
 #pragma unroll
-  for (int o = 0; o < NOUT; ++o) {
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock)
-      acc += __hip_atomic_load(&partials[(size_t)i * NOUT + o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tot[o] = block_sum(acc, lds);
+  for (int o = 0; o < NOUT; ++o) acc[o] = 0.0;
+  for (int i0 = threadIdx.x; i0 < (int)gridDim.x; i0 += 4 * kBlock) {      // one round trip per batch of 4 NOUT loads (see grid_finish)
+    double v[4][NOUT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + u * kBlock, (int)gridDim.x - 1);
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) v[u][o] = __hip_atomic_load(&partials[(size_t)i * NOUT + o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) acc[o] = (i0 + u * kBlock < (int)gridDim.x) ? acc[o] + v[u][o] : acc[o];
   }
+  block_sum_n<NOUT>(acc, tot);
+  (void)lds;
   if (threadIdx.x == 0) fn(tot);
 }
 

@@ -163,7 +163,7 @@ class GpuChol {
   double* d_y_ = nullptr;         // solution in the new ordering
   int* d_fail_ = nullptr;
   long long* d_prof_ = nullptr;   // MGB_CHOL_PROF=1: phase stamps of workgroup 0 of every factorisation launch
-  long long* d_wgprof_ = nullptr; // (-DMGB_PROF_PER_WG builds) start / end of every workgroup of every stamped launch
+  [[maybe_unused]] long long* d_wgprof_ = nullptr; // (-DMGB_PROF_PER_WG builds) start / end of every workgroup of every stamped launch
   GNode* d_nodes_ = nullptr;
   int* d_perm_ = nullptr;
   int* d_bdry_ = nullptr;

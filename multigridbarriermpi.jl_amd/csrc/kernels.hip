@@ -234,12 +234,13 @@ __global__ __launch_bounds__(kBlock) void trial_f0_kernel(int n, int N, BarrierP
     __syncthreads();
   }
   // per point: only its wave holds non-zero terms, so the block sums are those of the one-point kernel
-  double r[2 * NA];
+  double r[2 * NA], mine[2 * NA];
 #pragma unroll
   for (int a = 0; a < NA; ++a) {
-    r[2 * a] = block_sum(pa == a ? accF : 0.0, lds);
-    r[2 * a + 1] = block_sum(pa == a ? accL : 0.0, lds);
+    mine[2 * a] = pa == a ? accF : 0.0;
+    mine[2 * a + 1] = pa == a ? accL : 0.0;
   }
+  block_sum_n<2 * NA>(mine, r);      // one pair of barriers for all the points' sums
   // the partials go to the slot of the chunk sequence this block worked on, so the sums are those of the natural order;
   // results land at T.out_dev[0] .. (2 NA consecutive doubles: the points' (F, c.Dz) pairs) and its pinned host twin
   grid_finish<2 * NA>(r, scratch, T.out_dev, T.out_host, lds, sig, xcd_block(blockIdx.x, gridDim.x));
